@@ -1,0 +1,783 @@
+// oracle/orb_oracle.cpp -- TEST INFRASTRUCTURE ONLY (CPU restatement, not the product path).
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+// The shipped path is visual-slam_amd/csrc (HIP, gfx950) and never links or calls anything here.
+//
+// What it restates: the arithmetic behind the reference's ORBExtractor / DescriptorMatcher
+//   /root/reference/src/orbslam2/extractor.py:38-48  cv2.ORB_create(nfeatures, 1.2, 8, 31, 0, 2, HARRIS, 31, fastThreshold)
+//   /root/reference/src/orbslam2/extractor.py:61-65  cvtColor(BGR2GRAY) + orb.detectAndCompute(image, None)
+//   /root/reference/src/orbslam2/extractor.py:79-83  orb.compute(image, keypoints)
+//   /root/reference/src/orbslam2/matcher.py:29,70    BFMatcher(NORM_HAMMING).knnMatch(d1, d2, k=2)
+//   /root/reference/src/orbslam2/matcher.py:73-81    Lowe ratio loop
+// The arithmetic itself lives in the third-party dependency opencv-python (cv2), which is NOT in
+// /root/reference and is unpinned there.  This file restates the published
+// OpenCV 4.x algorithms (features2d orb/fast/keypoint, imgproc resize INTER_LINEAR_EXACT,
+// sepFilter2D 8-bit Gaussian, color BGR2GRAY, core batch_distance) from their public description.
+//
+// Pinning: steps gray -> pyramid -> FAST -> NMS -> border -> retainBest -> Harris -> retainBest ->
+// output order are pinned by the reference's 40 detector known-answer vectors
+// (data/groundtruth_matches/pairNN/gt.yaml keypoints1/2, see tests/test_oracle_kat.py).
+// IC angle, blur, rBRIEF bits, Hamming distances and match lists are PARITY UNPINNED against cv2
+// (no fixture of the reference holds them); they are pinned only by this restatement.
+//
+// Build: see oracle/Makefile (g++ -O2 -ffp-contract=off: float expressions must not be fused,
+// OpenCV's x86-64 baseline build has no FMA).
+
+#include <algorithm>
+#include <cfloat>
+#include <cstddef>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+typedef struct {
+    int32_t nfeatures;
+    float scale_factor;
+    int32_t nlevels;
+    int32_t edge_threshold;
+    int32_t fast_threshold;
+} orc_orb_params;
+}
+
+namespace {
+
+const float HARRIS_K = 0.04f;
+const int PATCH_SIZE = 31;
+const int HALF_PATCH = 15;
+
+static const int8_t kPattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+
+struct Img {
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;
+    Img() {}
+    Img(int w_, int h_) : w(w_), h(h_), px((size_t)w_ * h_) {}
+    const uint8_t* row(int y) const { return px.data() + (size_t)y * w; }
+    uint8_t* row(int y) { return px.data() + (size_t)y * w; }
+};
+
+inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+// ---- pyramid geometry: ORB_Impl::detectAndCompute getScale / level sizes ---------------------
+float level_scale(float scale_factor, int level) {
+    double sf = (double)scale_factor;  // member is double, constructed from the float argument
+    return (float)std::pow(sf, (double)level);
+}
+
+void level_size(int w, int h, float scale, int* lw, int* lh) {
+    float inv_scale = 1.0f / scale;
+    *lw = cv_round((float)w * inv_scale);
+    *lh = cv_round((float)h * inv_scale);
+}
+
+// ---- resize INTER_LINEAR_EXACT, 8UC1 (resize.cpp interpolationLinear<ufixedpoint16>) ---------
+struct LinCoef {
+    std::vector<int> ofs;
+    std::vector<uint16_t> c0, c1;
+};
+
+void linear_coeffs(int srcsize, int dstsize, LinCoef& lc) {
+    lc.ofs.assign(dstsize, 0);
+    lc.c0.assign(dstsize, 256);
+    lc.c1.assign(dstsize, 0);
+    double inv_scale = (double)dstsize / (double)srcsize;
+    double scale = 1.0 / inv_scale;
+    int minofst = 0, maxofst = dstsize;
+    for (int val = 0; val < dstsize; val++) {
+        double fval = scale * ((double)val + 0.5) - 0.5;
+        int ival = (int)std::floor(fval);
+        if (ival >= 0 && srcsize > 1) {
+            if (ival < srcsize - 1) {
+                lc.ofs[val] = ival;
+                double frac = fval - (double)ival;
+                int c1 = cv_round(frac * 256.0);
+                lc.c1[val] = (uint16_t)c1;
+                lc.c0[val] = (uint16_t)(256 - c1);
+            } else {
+                lc.ofs[val] = srcsize - 1;
+                maxofst = std::min(maxofst, val);
+            }
+        } else {
+            minofst = std::max(minofst, val + 1);
+        }
+    }
+    for (int val = 0; val < dstsize; val++) {
+        if (val < minofst) { lc.ofs[val] = 0; lc.c0[val] = 256; lc.c1[val] = 0; }
+        if (val >= maxofst) { lc.ofs[val] = srcsize - 1; lc.c0[val] = 256; lc.c1[val] = 0; }
+    }
+}
+
+void resize_linear_exact(const Img& src, Img& dst) {
+    LinCoef cx, cy;
+    linear_coeffs(src.w, dst.w, cx);
+    linear_coeffs(src.h, dst.h, cy);
+    for (int y = 0; y < dst.h; y++) {
+        int oy = cy.ofs[y];
+        int oy1 = std::min(oy + 1, src.h - 1);
+        const uint8_t* r0 = src.row(oy);
+        const uint8_t* r1 = src.row(oy1);
+        uint32_t my0 = cy.c0[y], my1 = cy.c1[y];
+        uint8_t* d = dst.row(y);
+        for (int x = 0; x < dst.w; x++) {
+            int ox = cx.ofs[x];
+            int ox1 = std::min(ox + 1, src.w - 1);
+            uint32_t mx0 = cx.c0[x], mx1 = cx.c1[x];
+            uint32_t h0 = mx0 * r0[ox] + mx1 * r0[ox1];  // ufixedpoint16, 8 fractional bits
+            uint32_t h1 = mx0 * r1[ox] + mx1 * r1[ox1];
+            uint32_t v = my0 * h0 + my1 * h1;            // ufixedpoint32, 16 fractional bits
+            d[x] = (uint8_t)((v + 32768u) >> 16);
+        }
+    }
+}
+
+void build_pyramid(const Img& gray, const orc_orb_params& p, int nlevels, std::vector<Img>& pyr,
+                   std::vector<float>& scales) {
+    pyr.resize(nlevels);
+    scales.resize(nlevels);
+    for (int L = 0; L < nlevels; L++) {
+        scales[L] = level_scale(p.scale_factor, L);
+        int lw, lh;
+        level_size(gray.w, gray.h, scales[L], &lw, &lh);
+        if (L == 0) {
+            pyr[0] = gray;  // scale 1.0 -> same size, plain copy
+        } else {
+            pyr[L] = Img(lw, lh);
+            if (lw > 0 && lh > 0) resize_linear_exact(pyr[L - 1], pyr[L]);
+        }
+    }
+}
+
+// ---- FAST-9/16 with score and 3x3 non-max suppression (fast.cpp FAST_t<16>, fast_score.cpp) -
+static const int kCircle[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1},
+                                   {2, -2}, {1, -3},  {0, -3},  {-1, -3}, {-2, -2}, {-3, -1},
+                                   {-3, 0}, {-3, 1},  {-2, 2},  {-1, 3}};
+
+struct FastPt {
+    int x, y, score;
+};
+
+inline bool fast_is_corner(const int d[25], int t) {
+    // 9 contiguous circle pixels all darker than v - t (d = v - p > t) or all brighter (d < -t)
+    int count = 0;
+    for (int k = 0; k < 25; k++) {
+        if (d[k] > t) { if (++count > 8) return true; } else count = 0;
+    }
+    count = 0;
+    for (int k = 0; k < 25; k++) {
+        if (d[k] < -t) { if (++count > 8) return true; } else count = 0;
+    }
+    return false;
+}
+
+inline int fast_corner_score(const int d[25], int threshold) {
+    // cornerScore<16>: largest threshold for which the pixel stays a corner
+    int a0 = threshold;
+    for (int k = 0; k < 16; k += 2) {
+        int a = std::min(d[k + 1], d[k + 2]);
+        a = std::min(a, d[k + 3]);
+        if (a <= a0) continue;
+        a = std::min(a, d[k + 4]);
+        a = std::min(a, d[k + 5]);
+        a = std::min(a, d[k + 6]);
+        a = std::min(a, d[k + 7]);
+        a = std::min(a, d[k + 8]);
+        a0 = std::max(a0, std::min(a, d[k]));
+        a0 = std::max(a0, std::min(a, d[k + 9]));
+    }
+    int b0 = -a0;
+    for (int k = 0; k < 16; k += 2) {
+        int b = std::max(d[k + 1], d[k + 2]);
+        b = std::max(b, d[k + 3]);
+        b = std::max(b, d[k + 4]);
+        b = std::max(b, d[k + 5]);
+        if (b >= b0) continue;
+        b = std::max(b, d[k + 6]);
+        b = std::max(b, d[k + 7]);
+        b = std::max(b, d[k + 8]);
+        b0 = std::min(b0, std::max(b, d[k]));
+        b0 = std::min(b0, std::max(b, d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+void fast9_nms(const Img& img, int threshold, std::vector<FastPt>& out) {
+    out.clear();
+    int w = img.w, h = img.h;
+    if (w < 7 || h < 7) return;
+    threshold = std::min(std::max(threshold, 0), 255);
+    std::vector<uint8_t> score((size_t)w * h, 0), corner((size_t)w * h, 0);
+    for (int y = 3; y < h - 3; y++) {
+        for (int x = 3; x < w - 3; x++) {
+            int v = img.row(y)[x];
+            int d[25];
+            for (int k = 0; k < 16; k++) d[k] = v - img.row(y + kCircle[k][1])[x + kCircle[k][0]];
+            for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+            if (fast_is_corner(d, threshold)) {
+                corner[(size_t)y * w + x] = 1;
+                score[(size_t)y * w + x] = (uint8_t)fast_corner_score(d, threshold);
+            }
+        }
+    }
+    for (int y = 3; y < h - 3; y++) {
+        for (int x = 3; x < w - 3; x++) {
+            if (!corner[(size_t)y * w + x]) continue;
+            int s = score[(size_t)y * w + x];
+            const uint8_t* pp = &score[(size_t)(y - 1) * w + x];
+            const uint8_t* pc = &score[(size_t)y * w + x];
+            const uint8_t* pn = &score[(size_t)(y + 1) * w + x];
+            if (s > pc[1] && s > pc[-1] && s > pp[-1] && s > pp[0] && s > pp[1] && s > pn[-1] &&
+                s > pn[0] && s > pn[1])
+                out.push_back({x, y, s});
+        }
+    }
+}
+
+// ---- KeyPointsFilter::retainBest (keypoint.cpp) on libstdc++ ---------------------------------
+struct RespGreater {
+    bool operator()(const orc_keypoint& a, const orc_keypoint& b) const { return a.response > b.response; }
+};
+
+// Which C++ standard library the cv2 wheel was linked against decides the ORDER std::nth_element
+// leaves the survivors in (the SET is the same).  The reference's gt.yaml fixtures were produced by a
+// wheel using the MSVC STL (Windows): their per-level order shows MSVC's signature (an unsorted
+// partition prefix followed by an insertion-sorted run of <= 32).  Linux wheels use libstdc++.
+//   stl 0 = libstdc++ introselect (std::nth_element of this toolchain), 1 = MSVC STL (restated below).
+int g_stl = 1;
+int g_nth_variant = 0;  // experiment switch: 0 = nth at n_points-1 (OpenCV >= 4.5.3), 1 = nth at n_points (older)
+
+// --- MSVC STL <algorithm> nth_element, restated from the published microsoft/STL sources ---------
+namespace msvc {
+typedef std::vector<orc_keypoint>::iterator It;
+const int ISORT_MAX = 32;
+
+template <class Pr> void med3(It first, It mid, It last, Pr pred) {
+    if (pred(*mid, *first)) std::iter_swap(mid, first);
+    if (pred(*last, *mid)) {
+        std::iter_swap(last, mid);
+        if (pred(*mid, *first)) std::iter_swap(mid, first);
+    }
+}
+
+template <class Pr> void guess_median(It first, It mid, It last, Pr pred) {  // last inclusive
+    const std::ptrdiff_t count = last - first;
+    if (40 < count) {  // Tukey's ninther
+        const std::ptrdiff_t step = (count + 1) >> 3;
+        const std::ptrdiff_t two_step = step << 1;
+        med3(first, first + step, first + two_step, pred);
+        med3(mid - step, mid, mid + step, pred);
+        med3(last - two_step, last - step, last, pred);
+        med3(first + step, mid, last - step, pred);
+    } else {
+        med3(first, mid, last, pred);
+    }
+}
+
+template <class Pr> std::pair<It, It> partition_by_median_guess(It first, It last, Pr pred) {
+    It mid = first + ((last - first) >> 1);
+    guess_median(first, mid, last - 1, pred);
+    It pfirst = mid;
+    It plast = pfirst + 1;
+    while (first < pfirst && !pred(*(pfirst - 1), *pfirst) && !pred(*pfirst, *(pfirst - 1))) --pfirst;
+    while (plast < last && !pred(*plast, *pfirst) && !pred(*pfirst, *plast)) ++plast;
+    It gfirst = plast;
+    It glast = pfirst;
+    for (;;) {
+        for (; gfirst < last; ++gfirst) {
+            if (pred(*pfirst, *gfirst)) continue;
+            else if (pred(*gfirst, *pfirst)) break;
+            else if (plast != gfirst) { std::iter_swap(plast, gfirst); ++plast; }
+            else ++plast;
+        }
+        for (; first < glast; --glast) {
+            if (pred(*(glast - 1), *pfirst)) continue;
+            else if (pred(*pfirst, *(glast - 1))) break;
+            else if (--pfirst != glast - 1) std::iter_swap(pfirst, glast - 1);
+        }
+        if (glast == first && gfirst == last) return std::make_pair(pfirst, plast);
+        if (glast == first) {  // no room at bottom, rotate pivot upward
+            if (plast != gfirst) std::iter_swap(pfirst, plast);
+            ++plast;
+            std::iter_swap(pfirst, gfirst);
+            ++pfirst;
+            ++gfirst;
+        } else if (gfirst == last) {  // no room at top, rotate pivot downward
+            if (--glast != --pfirst) std::iter_swap(glast, pfirst);
+            std::iter_swap(pfirst, --plast);
+        } else {
+            std::iter_swap(gfirst, --glast);
+            ++gfirst;
+        }
+    }
+}
+
+template <class Pr> void insertion_sort(It first, It last, Pr pred) {
+    if (first == last) return;
+    for (It mid = first; ++mid != last;) {
+        It hole = mid;
+        orc_keypoint val = *mid;
+        if (pred(val, *first)) {
+            std::move_backward(first, mid, ++hole);
+            *first = val;
+        } else {
+            for (It prev = hole; pred(val, *--prev); hole = prev) *hole = *prev;
+            *hole = val;
+        }
+    }
+}
+
+template <class Pr> void nth_element(It first, It nth, It last, Pr pred) {
+    if (nth == last) return;
+    while (ISORT_MAX < last - first) {
+        std::pair<It, It> m = partition_by_median_guess(first, last, pred);
+        if (m.second <= nth) first = m.second;
+        else if (m.first <= nth) return;
+        else last = m.first;
+    }
+    insertion_sort(first, last, pred);
+}
+}  // namespace msvc
+
+void retain_best(std::vector<orc_keypoint>& kps, int n_points) {
+    if (n_points >= 0 && kps.size() > (size_t)n_points) {
+        if (n_points == 0) { kps.clear(); return; }
+        auto nth = kps.begin() + n_points - 1 + g_nth_variant;
+        if (g_stl == 1) msvc::nth_element(kps.begin(), nth, kps.end(), RespGreater());
+        else std::nth_element(kps.begin(), nth, kps.end(), RespGreater());
+        float ambiguous = kps[n_points - 1].response;
+        // std::partition (bidirectional form; libstdc++ and MSVC produce the same permutation)
+        auto new_end = std::partition(kps.begin() + n_points, kps.end(),
+                                      [ambiguous](const orc_keypoint& k) { return k.response >= ambiguous; });
+        kps.resize(new_end - kps.begin());
+    }
+}
+
+// ---- Harris response on the raw level (orb.cpp HarrisResponses, blockSize 7) -----------------
+float harris_response(const Img& img, int x0, int y0) {
+    const int bs = 7, r = bs / 2;
+    float scale = 1.f / ((1 << 2) * bs * 255.f);
+    float scale_sq_sq = scale * scale * scale * scale;
+    int a = 0, b = 0, c = 0;
+    for (int i = 0; i < bs; i++) {
+        for (int j = 0; j < bs; j++) {
+            int y = y0 - r + i, x = x0 - r + j;
+            const uint8_t* pm = img.row(y - 1) + x;
+            const uint8_t* p0 = img.row(y) + x;
+            const uint8_t* pp = img.row(y + 1) + x;
+            int Ix = (p0[1] - p0[-1]) * 2 + (pm[1] - pm[-1]) + (pp[1] - pp[-1]);
+            int Iy = (pp[0] - pm[0]) * 2 + (pp[-1] - pm[-1]) + (pp[1] - pm[1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            c += Ix * Iy;
+        }
+    }
+    float fa = (float)a, fb = (float)b, fc = (float)c;
+    float t1 = fa * fb;
+    float t2 = fc * fc;
+    float s = fa + fb;
+    float t3 = HARRIS_K * s;
+    float t4 = t3 * s;
+    return ((t1 - t2) - t4) * scale_sq_sq;
+}
+
+// ---- intensity-centroid angle (orb.cpp ICAngles + mathfuncs fastAtan2) -----------------------
+void make_umax(int umax[HALF_PATCH + 2]) {
+    int vmax = (int)std::floor(HALF_PATCH * std::sqrt(2.f) / 2 + 1);
+    int vmin = (int)std::ceil(HALF_PATCH * std::sqrt(2.f) / 2);
+    for (int v = 0; v <= vmax; ++v) umax[v] = cv_round(std::sqrt((double)HALF_PATCH * HALF_PATCH - v * v));
+    for (int v = HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (umax[v0] == umax[v0 + 1]) ++v0;
+        umax[v] = v0;
+        ++v0;
+    }
+}
+
+float fast_atan2(float y, float x) {
+    static const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    static const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    static const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    static const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+float ic_angle(const Img& img, int cx, int cy, const int* umax) {
+    int m_01 = 0, m_10 = 0;
+    const uint8_t* center = img.row(cy) + cx;
+    int step = img.w;
+    for (int u = -HALF_PATCH; u <= HALF_PATCH; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= HALF_PATCH; ++v) {
+        int v_sum = 0;
+        int d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int val_plus = center[u + v * step], val_minus = center[u - v * step];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    return fast_atan2((float)m_01, (float)m_10);
+}
+
+// ---- GaussianBlur(7x7, sigma 2, REFLECT_101) as ORB calls it -----------------------------------
+// ORB blurs a sub-matrix view of its pyramid buffer without BORDER_ISOLATED, so GaussianBlur takes
+// the sepFilter2D route: the float kernel is quantised to 8 fractional bits (cvRound(k*256)), rows
+// and columns are integer sums, result = (sum + 2^15) >> 16 saturated to u8.
+void gaussian_kernel_q8(int kq[7]) {
+    double k[7], sum = 0;
+    const double sigma = 2.0;
+    double scale2x = -0.125 / (sigma * sigma);  // -0.5/sigma^2 with x = 2*(i - 3)
+    for (int i = 0; i < 7; i++) {
+        double x = 2.0 * i - 6.0;  // x = 1-n step 2
+        k[i] = std::exp(x * x * scale2x);
+        sum += k[i];
+    }
+    double mul1 = 1.0 / sum;  // getGaussianKernelBitExact normalises by multiplying with 1/sum
+    for (int i = 0; i < 7; i++) {
+        float kf = (float)(k[i] * mul1);
+        kq[i] = cv_round(kf * 256.f);  // Mat::convertTo(CV_32S, 256): saturate_cast<int>(float) = round-half-even
+    }
+}
+
+void gaussian_blur7(const Img& src, Img& dst) {
+    int kq[7];
+    gaussian_kernel_q8(kq);
+    int w = src.w, h = src.h;
+    dst = Img(w, h);
+    std::vector<int> rowbuf((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* s = src.row(y);
+        int* r = &rowbuf[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int i = -3; i <= 3; i++) acc += kq[i + 3] * s[reflect101(x + i, w)];
+            r[x] = acc;
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        uint8_t* d = dst.row(y);
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int j = -3; j <= 3; j++) acc += kq[j + 3] * rowbuf[(size_t)reflect101(y + j, h) * w + x];
+            int v = (acc + (1 << 15)) >> 16;
+            d[x] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
+    }
+}
+
+// pixel of a blurred level at (x, y) possibly outside the level: OpenCV reads its 32-px
+// REFLECT_101 apron there, which holds UNBLURRED reflected pixels (the blur writes the ROI only).
+inline int desc_pixel(const Img& raw, const Img& blur, int x, int y) {
+    if (x >= 0 && x < blur.w && y >= 0 && y < blur.h) return blur.row(y)[x];
+    return raw.row(reflect101(y, raw.h))[reflect101(x, raw.w)];
+}
+
+// ---- rBRIEF (orb.cpp computeOrbDescriptors, WTA_K = 2) ---------------------------------------
+void orb_descriptor(const Img& raw, const Img& blur, int cx, int cy, float angle_deg, uint8_t desc[32]) {
+    float angle = angle_deg;
+    angle *= (float)(M_PI / 180.f);
+    float a = (float)std::cos((double)angle), b = (float)std::sin((double)angle);
+    for (int i = 0; i < 32; i++) {
+        int val = 0;
+        for (int k = 0; k < 8; k++) {
+            const int8_t* pt = &kPattern[(i * 8 + k) * 4];
+            float x0 = (float)pt[0] * a - (float)pt[1] * b;
+            float y0 = (float)pt[0] * b + (float)pt[1] * a;
+            float x1 = (float)pt[2] * a - (float)pt[3] * b;
+            float y1 = (float)pt[2] * b + (float)pt[3] * a;
+            int t0 = desc_pixel(raw, blur, cx + cv_round(x0), cy + cv_round(y0));
+            int t1 = desc_pixel(raw, blur, cx + cv_round(x1), cy + cv_round(y1));
+            val |= (t0 < t1) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+void quotas(const orc_orb_params& p, std::vector<int>& q) {
+    int nlevels = p.nlevels;
+    q.assign(nlevels, 0);
+    float factor = (float)(1.0 / (double)p.scale_factor);
+    float nd = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int L = 0; L < nlevels - 1; L++) {
+        q[L] = cv_round(nd);
+        sum += q[L];
+        nd *= factor;
+    }
+    q[nlevels - 1] = std::max(p.nfeatures - sum, 0);
+}
+
+// computeKeyPoints (orb.cpp) for the HARRIS score type
+void compute_keypoints(const std::vector<Img>& pyr, const std::vector<float>& scales, const orc_orb_params& p,
+                       std::vector<orc_keypoint>& all) {
+    int nlevels = (int)pyr.size();
+    std::vector<int> q;
+    quotas(p, q);
+    int umax[HALF_PATCH + 2];
+    make_umax(umax);
+    all.clear();
+    std::vector<int> counters(nlevels, 0);
+    std::vector<orc_keypoint> kps;
+    std::vector<FastPt> fp;
+    for (int L = 0; L < nlevels; L++) {
+        const Img& img = pyr[L];
+        fast9_nms(img, p.fast_threshold, fp);
+        kps.clear();
+        int et = p.edge_threshold;
+        bool too_small = et > 0 && (img.h <= et * 2 || img.w <= et * 2);
+        if (!too_small) {
+            for (const FastPt& f : fp) {
+                if (et > 0 && !(f.x >= et && f.x < img.w - et && f.y >= et && f.y < img.h - et)) continue;
+                orc_keypoint k;
+                k.x = (float)f.x; k.y = (float)f.y; k.size = 7.f; k.angle = -1.f;
+                k.response = (float)f.score; k.octave = 0; k.class_id = -1;
+                kps.push_back(k);
+            }
+        }
+        retain_best(kps, 2 * q[L]);
+        counters[L] = (int)kps.size();
+        for (auto& k : kps) { k.octave = L; k.size = PATCH_SIZE * scales[L]; }
+        all.insert(all.end(), kps.begin(), kps.end());
+    }
+    if (all.empty()) return;
+    for (auto& k : all) k.response = harris_response(pyr[k.octave], cv_round(k.x), cv_round(k.y));
+    std::vector<orc_keypoint> out;
+    int offset = 0;
+    for (int L = 0; L < nlevels; L++) {
+        kps.assign(all.begin() + offset, all.begin() + offset + counters[L]);
+        offset += counters[L];
+        retain_best(kps, q[L]);
+        out.insert(out.end(), kps.begin(), kps.end());
+    }
+    all.swap(out);
+    for (auto& k : all) k.angle = ic_angle(pyr[k.octave], cv_round(k.x), cv_round(k.y), umax);
+    for (auto& k : all) {
+        float s = scales[k.octave];
+        k.x *= s;
+        k.y *= s;
+    }
+}
+
+void compute_descriptors(const std::vector<Img>& pyr, const std::vector<float>& scales,
+                         const std::vector<orc_keypoint>& kps, uint8_t* desc) {
+    int nlevels = (int)pyr.size();
+    std::vector<Img> blur(nlevels);
+    std::vector<char> need(nlevels, 0);
+    for (const auto& k : kps) need[k.octave] = 1;
+    for (int L = 0; L < nlevels; L++)
+        if (need[L] && pyr[L].w > 0 && pyr[L].h > 0) gaussian_blur7(pyr[L], blur[L]);
+    for (size_t j = 0; j < kps.size(); j++) {
+        const orc_keypoint& k = kps[j];
+        float scale = 1.f / scales[k.octave];
+        int cx = cv_round(k.x * scale), cy = cv_round(k.y * scale);
+        orb_descriptor(pyr[k.octave], blur[k.octave], cx, cy, k.angle, desc + j * 32);
+    }
+}
+
+Img wrap_gray(const uint8_t* g, int w, int h) {
+    Img im(w, h);
+    std::memcpy(im.px.data(), g, (size_t)w * h);
+    return im;
+}
+
+}  // namespace
+
+extern "C" {
+void orc_set_variant(int stl, int nth_variant) { g_stl = stl; g_nth_variant = nth_variant; }
+
+// cvtColor(COLOR_BGR2GRAY), 8-bit: fixed-point 15-bit coefficients (color_yuv, OpenCV 4.x)
+void orc_bgr2gray(const uint8_t* bgr, int w, int h, uint8_t* gray) {
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+        gray[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+// level geometry + per-level quotas (for tests and for sizing host buffers)
+void orc_levels(int w, int h, const orc_orb_params* p, int* lw, int* lh, float* scale, int* quota) {
+    std::vector<int> q;
+    quotas(*p, q);
+    for (int L = 0; L < p->nlevels; L++) {
+        scale[L] = level_scale(p->scale_factor, L);
+        level_size(w, h, scale[L], &lw[L], &lh[L]);
+        quota[L] = q[L];
+    }
+}
+
+// pyramid level L (raw and/or blurred) into caller buffers of lw*lh bytes (NULL to skip)
+int orc_pyramid_level(const uint8_t* gray, int w, int h, const orc_orb_params* p, int level, uint8_t* raw,
+                      uint8_t* blurred) {
+    Img g = wrap_gray(gray, w, h);
+    std::vector<Img> pyr;
+    std::vector<float> scales;
+    build_pyramid(g, *p, level + 1, pyr, scales);
+    const Img& im = pyr[level];
+    if (raw) std::memcpy(raw, im.px.data(), im.px.size());
+    if (blurred) {
+        Img b;
+        gaussian_blur7(im, b);
+        std::memcpy(blurred, b.px.data(), b.px.size());
+    }
+    return 0;
+}
+
+// FAST-9 + NMS candidates of one level in raster order (x, y, score triplets); returns count
+int orc_fast_level(const uint8_t* img, int w, int h, int threshold, int32_t* xys, int cap) {
+    Img im = wrap_gray(img, w, h);
+    std::vector<FastPt> fp;
+    fast9_nms(im, threshold, fp);
+    int n = 0;
+    for (const FastPt& f : fp) {
+        if (n < cap) { xys[3 * n] = f.x; xys[3 * n + 1] = f.y; xys[3 * n + 2] = f.score; }
+        n++;
+    }
+    return n;
+}
+
+// retainBest on a bare response array: writes the surviving original indices in output order
+int orc_retain_best(const float* resp, int n, int n_points, int32_t* order) {
+    std::vector<orc_keypoint> k(n);
+    for (int i = 0; i < n; i++) { k[i].response = resp[i]; k[i].class_id = i; }
+    retain_best(k, n_points);
+    for (size_t i = 0; i < k.size(); i++) order[i] = k[i].class_id;
+    return (int)k.size();
+}
+
+float orc_harris(const uint8_t* img, int w, int h, int x, int y) {
+    Img im = wrap_gray(img, w, h);
+    return harris_response(im, x, y);
+}
+
+float orc_ic_angle(const uint8_t* img, int w, int h, int x, int y) {
+    int umax[HALF_PATCH + 2];
+    make_umax(umax);
+    Img im = wrap_gray(img, w, h);
+    return ic_angle(im, x, y, umax);
+}
+
+float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+
+// detectAndCompute(gray, None): returns number of keypoints (may exceed nfeatures through ties).
+// desc may be NULL (detect only).
+int orc_orb_detect_compute(const uint8_t* gray, int w, int h, const orc_orb_params* p, orc_keypoint* kps,
+                           uint8_t* desc, int cap) {
+    Img g = wrap_gray(gray, w, h);
+    std::vector<Img> pyr;
+    std::vector<float> scales;
+    build_pyramid(g, *p, p->nlevels, pyr, scales);
+    std::vector<orc_keypoint> all;
+    compute_keypoints(pyr, scales, *p, all);
+    int n = (int)all.size();
+    if (n > cap) return -n;
+    if (n && kps) std::memcpy(kps, all.data(), sizeof(orc_keypoint) * n);
+    if (n && desc) compute_descriptors(pyr, scales, all, desc);
+    return n;
+}
+
+// compute(gray, keypoints): border filter on the full image, regroup by octave if unsorted,
+// no angle recomputation.  kept_idx[i] = index into kps_in of output row i.
+int orc_orb_compute(const uint8_t* gray, int w, int h, const orc_orb_params* p, const orc_keypoint* kps_in,
+                    int n_in, int32_t* kept_idx, uint8_t* desc) {
+    Img g = wrap_gray(gray, w, h);
+    int nlevels = 0;
+    bool sorted = true;
+    for (int i = 0; i < n_in; i++) {
+        int L = kps_in[i].octave;
+        if (L < 0) return -1;
+        if (i > 0 && L < kps_in[i - 1].octave) sorted = false;
+        nlevels = std::max(nlevels, L);
+    }
+    nlevels++;
+    std::vector<Img> pyr;
+    std::vector<float> scales;
+    build_pyramid(g, *p, nlevels, pyr, scales);
+    std::vector<int> keep;
+    int et = p->edge_threshold;
+    if (!(et > 0 && (h <= et * 2 || w <= et * 2))) {
+        for (int i = 0; i < n_in; i++) {
+            int x = cv_round(kps_in[i].x), y = cv_round(kps_in[i].y);
+            if (et > 0 && !(x >= et && x < w - et && y >= et && y < h - et)) continue;
+            keep.push_back(i);
+        }
+    }
+    if (!sorted) {
+        std::vector<int> re;
+        for (int L = 0; L < nlevels; L++)
+            for (int i : keep)
+                if (kps_in[i].octave == L) re.push_back(i);
+        keep.swap(re);
+    }
+    std::vector<orc_keypoint> kk;
+    for (int i : keep) kk.push_back(kps_in[i]);
+    for (size_t i = 0; i < keep.size(); i++) kept_idx[i] = keep[i];
+    if (!kk.empty()) compute_descriptors(pyr, scales, kk, desc);
+    return (int)kk.size();
+}
+
+// BFMatcher(NORM_HAMMING).knnMatch(k=2): per query the two smallest (distance, trainIdx) pairs,
+// ties resolved towards the lower trainIdx (batch_distance.cpp strict '<' insertion).
+// idx/dist are [nq*2]; missing neighbours are idx -1, dist INT_MAX.
+void orc_match_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+    for (int i = 0; i < nq; i++) {
+        int d0 = INT32_MAX, d1 = INT32_MAX, i0 = -1, i1 = -1;
+        const uint64_t* a = (const uint64_t*)(q + (size_t)i * 32);
+        uint64_t a0, a1, a2, a3;
+        std::memcpy(&a0, a, 8); std::memcpy(&a1, a + 1, 8); std::memcpy(&a2, a + 2, 8); std::memcpy(&a3, a + 3, 8);
+        for (int j = 0; j < nt; j++) {
+            uint64_t b[4];
+            std::memcpy(b, t + (size_t)j * 32, 32);
+            int d = __builtin_popcountll(a0 ^ b[0]) + __builtin_popcountll(a1 ^ b[1]) +
+                    __builtin_popcountll(a2 ^ b[2]) + __builtin_popcountll(a3 ^ b[3]);
+            if (d < d1) {
+                if (d0 > d) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
+                else { d1 = d; i1 = j; }
+            }
+        }
+        idx[2 * i] = i0; idx[2 * i + 1] = i1;
+        dist[2 * i] = d0; dist[2 * i + 1] = d1;
+    }
+}
+
+// matcher.py:73-81: keep m if (no second neighbour) or (not ratio_test) or m.distance < ratio * n.distance
+// (Python float compare = IEEE double).  pass[i] in {0,1}; queries without any neighbour get 0.
+void orc_ratio_test(const int32_t* idx, const int32_t* dist, int nq, double ratio, int ratio_test, uint8_t* pass) {
+    for (int i = 0; i < nq; i++) {
+        if (idx[2 * i] < 0) { pass[i] = 0; continue; }
+        if (idx[2 * i + 1] < 0 || !ratio_test) { pass[i] = 1; continue; }
+        double m = (double)(float)dist[2 * i], n = (double)(float)dist[2 * i + 1];
+        pass[i] = m < ratio * n ? 1 : 0;
+    }
+}
+
+}  // extern "C"
