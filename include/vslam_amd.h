@@ -1,0 +1,156 @@
+/* vslam_amd.h -- C-ABI of the MI355X-native ORB front-end (libvslam_amd.so).
+ *
+ * Drop-in boundary for ONE hot path of p2004dr/visual-slam: extract -> match -> two-view
+ * initialisation.  The reference has no FFI layer; its boundary is the Python class API that
+ * Tracker calls.  Each entry point below replaces the cv2 call(s) behind one reference method
+ * (file:line relative to the reference tree) and is bound by the ctypes host classes in
+ * visual-slam_amd/orbslam2/ which keep the reference's constructors and method signatures.
+ *
+ * Conventions: plain C, opaque context, caller-allocated outputs, int status (0 = MO_OK, <0 = error,
+ * text via mo_last_error), no exceptions cross the boundary, no torch types.  One context is
+ * thread-compatible (one caller at a time), like the single-threaded reference.
+ * "host" entry points take host pointers and do the H2D/D2H themselves; "mo_dev_*" entry points take
+ * DEVICE pointers (inputs already resident in HBM) and enqueue on the context's stream without
+ * synchronising, for the batched / multi-GPU mode and the benchmark.
+ */
+#ifndef VSLAM_AMD_H
+#define VSLAM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MO_OK 0
+#define MO_ERR_ARG (-1)       /* bad argument */
+#define MO_ERR_HIP (-2)       /* HIP runtime error (see mo_last_error) */
+#define MO_ERR_CAPACITY (-3)  /* caller buffer or internal capacity too small */
+#define MO_ERR_UNSUPPORTED (-4)
+
+#define MO_ORDER_LIBSTDCXX 0 /* retainBest order of cv2 wheels linked against libstdc++ (Linux) */
+#define MO_ORDER_MSVC 1      /* retainBest order of cv2 wheels linked against the MSVC STL (Windows);
+                                the order of the reference's gt.yaml fixtures */
+
+typedef struct mo_ctx mo_ctx;
+
+/* same fields as cv2.KeyPoint: pt, size, angle, response, octave, class_id (28 bytes) */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} mo_keypoint;
+
+/* cv2.ORB_create arguments as the reference passes them (src/orbslam2/extractor.py:38-48).
+ * Only the values the reference uses are implemented: edge_threshold any >= 19 (31 in the reference),
+ * first_level 0, wta_k 2, score_type 0 (HARRIS), patch_size 31. */
+typedef struct {
+    int32_t nfeatures;      /* extractor.py:39 */
+    float scale_factor;     /* extractor.py:40 */
+    int32_t nlevels;        /* extractor.py:41, 1..12 */
+    int32_t edge_threshold; /* extractor.py:42 */
+    int32_t first_level;    /* extractor.py:43 */
+    int32_t wta_k;          /* extractor.py:44 */
+    int32_t score_type;     /* extractor.py:45, 0 = HARRIS_SCORE */
+    int32_t patch_size;     /* extractor.py:46 */
+    int32_t fast_threshold; /* extractor.py:47 (= min_threshold) */
+    int32_t select_order;   /* MO_ORDER_*: which STL's nth_element permutation to reproduce */
+} mo_orb_params;
+
+/* ---- context ------------------------------------------------------------------------------ */
+mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch);
+void mo_destroy(mo_ctx*);
+const char* mo_last_error(mo_ctx*); /* valid until the next call on ctx; ctx may be NULL (creation errors) */
+int mo_set_stream(mo_ctx*, void* hip_stream); /* NULL = the context's own stream */
+int mo_sync(mo_ctx*);                         /* hipStreamSynchronize on the context stream */
+int mo_device_count(void);                    /* hipGetDeviceCount, 0 when there is no GPU */
+
+/* ---- ORBExtractor ----------------------------------------------------------------------- */
+/* Replaces cv2.cvtColor + orb.detectAndCompute(image, None)   (extractor.py:61-65, detect_and_compute).
+ * img: batch images, u8, ch = 1 (gray) or 3 (BGR), row stride in bytes, images packed at stride*h.
+ * kps [batch*cap], desc [batch*cap*32] (may be NULL = detect only), counts [batch].
+ * Returns MO_ERR_CAPACITY if a frame yields more than cap keypoints (counts then holds the needs). */
+int mo_orb_detect_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int w, int h, int stride, int ch,
+                          int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts);
+
+/* Replaces orb.compute(image, keypoints)   (extractor.py:79-83 compute, :140 distribute_keypoints).
+ * Keeps cv2's behaviour: keypoints within edge_threshold of the image border are dropped, kp.angle is
+ * used as supplied (no re-orientation), kp.octave selects the level.  kept_idx[i] = index into kps_in
+ * of descriptor row i; n_out = number of rows. */
+int mo_orb_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int w, int h, int stride, int ch,
+                   const mo_keypoint* kps_in, int n_in, int32_t* kept_idx, uint8_t* desc, int* n_out);
+
+/* ---- DescriptorMatcher ------------------------------------------------------------------- */
+/* Replaces BFMatcher(NORM_HAMMING).knnMatch(d1, d2, k=2) + the Lowe ratio loop (matcher.py:70,73-81).
+ * q [batch][nq][32], t [batch][nt][32]; ratio NULL = no ratio test (ratio_test=False).
+ * train_idx/dist [batch][nq][2] (missing neighbour: idx -1, dist INT32_MAX), pass [batch][nq]. */
+int mo_match_knn2_ratio(mo_ctx*, const uint8_t* q, int nq, const uint8_t* t, int nt, const double* ratio,
+                        int batch, int32_t* train_idx, int32_t* dist, uint8_t* pass);
+
+/* ---- MapInitializer ---------------------------------------------------------------------- */
+/* Replaces calculate_essential_matrix + recover_pose + triangulate_points + the cheirality loop
+ * (initializer.py:79-120; utils.py:56-70,120-160).  8-point essential-matrix RANSAC over n_hyp
+ * hypotheses scored in parallel, least-squares refit on the consensus set, recoverPose-style
+ * cheirality vote (depth in (0, 50)), DLT triangulation.
+ * p1,p2 [m][2] pixel coordinates; K row-major 3x3; thr_px Sampson threshold in pixels; prob is
+ * accepted for signature compatibility (all n_hyp hypotheses are always scored).
+ * Outputs: R [9] row-major, t [3] unit norm, E [9] (may be NULL), inlier [m] = pose mask (RANSAC inlier
+ * AND cheirality of the winning pose), X [m][3] triangulated points (valid where inlier), n_good. */
+int mo_init_two_view(mo_ctx*, const float* p1, const float* p2, int m, const double K[9], double thr_px,
+                     double prob, int n_hyp, uint64_t seed, double R[9], double t[3], double E[9],
+                     uint8_t* ransac_inlier /* [m] findEssentialMat mask, may be NULL */, uint8_t* inlier, float* X,
+                     int* n_good);
+
+/* Replaces cv2.triangulatePoints(P1, P2, pts1, pts2)   (utils.py:56-60): per-point 4x4 DLT null vector.
+ * P1, P2 row-major 3x4 f64; p1, p2 [n][2] f32; X4 [n][4] f32 homogeneous (unit norm, sign arbitrary -
+ * the reference divides by w, utils.py:62-70). */
+int mo_triangulate_points(mo_ctx*, const double P1[12], const double P2[12], const float* p1, const float* p2, int n,
+                          float* X4);
+
+/* ---- device-resident batched mode (frames independent; shards across GPUs by frame) -------- */
+typedef struct {
+    /* inputs */
+    const uint8_t* d_gray;  /* [batch][h][w] u8, device */
+    int32_t w, h, batch;
+    int32_t cap;            /* keypoint capacity per frame */
+    double ratio;           /* Lowe ratio, <= 0 disables the test */
+    double K[9];            /* intrinsics for the two-view stage */
+    double thr_px;          /* RANSAC threshold (initializer.py:79 passes 3.0) */
+    int32_t n_hyp;          /* hypotheses per pair, 0 = skip the two-view stage */
+    uint64_t seed;
+    /* outputs, all device pointers */
+    mo_keypoint* d_kps;     /* [batch][cap] */
+    uint8_t* d_desc;        /* [batch][cap][32] */
+    int32_t* d_counts;      /* [batch] */
+    int32_t* d_match_idx;   /* [batch-1][cap][2]  pair i = frame i (query) vs frame i+1 (train) */
+    int32_t* d_match_dist;  /* [batch-1][cap][2] */
+    uint8_t* d_match_pass;  /* [batch-1][cap] */
+    double* d_pose;         /* [batch-1][12] R (9) then t (3); may be NULL when n_hyp == 0 */
+    float* d_points;        /* [batch-1][cap][3] triangulated points per query keypoint (NaN = none) */
+    int32_t* d_n_points;    /* [batch-1] number of valid map points per pair */
+} mo_batch_io;
+
+/* One pass of the hot path over a batch: extract every frame, match consecutive frames, two-view pose +
+ * map points per pair.  Enqueues on the context stream; call mo_sync (or sync the stream) before reading. */
+int mo_dev_frontend_batch(mo_ctx*, const mo_orb_params*, const mo_batch_io*);
+int mo_dev_orb_detect_compute(mo_ctx*, const mo_orb_params*, const uint8_t* d_gray, int w, int h, int batch,
+                              mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
+/* pairs: q/t frame indices into d_desc [*][cap][32] with per-frame counts d_counts */
+int mo_dev_match_pairs(mo_ctx*, const uint8_t* d_desc, const int32_t* d_counts, int cap, const int32_t* d_qf,
+                       const int32_t* d_tf, int n_pairs, double ratio, int32_t* d_idx, int32_t* d_dist,
+                       uint8_t* d_pass);
+
+/* per-stage device time of the last mo_dev_* call, measured with hipEvents on the context stream.
+ * names: NULL-terminated array of stage names owned by the library; ms [n] filled. Returns n stages. */
+int mo_stage_times(mo_ctx*, const char*** names, float* ms, int cap);
+
+/* internal-stage probes used by the parity tests (device pipeline, host in/out) */
+int mo_dbg_pyramid_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level, int blurred,
+                         uint8_t* out /* lw*lh */, int* lw, int* lh);
+int mo_dbg_fast_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level,
+                      int32_t* xys /* [cap][3] */, int cap, int* n);
+int mo_dbg_retain_best(mo_ctx*, const float* resp, int n, int n_points, int select_order, int32_t* order, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

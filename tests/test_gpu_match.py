@@ -1,0 +1,60 @@
+"""GPU parity of the brute-force Hamming 2-NN + ratio test vs the CPU oracle (bit-exact indices/distances)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vslam_amd as V
+    c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=4)
+    yield c
+    c.close()
+
+
+def _check(ctx, q, t, ratio):
+    from oracle import orb_oracle as O
+    idx, dist, ps = ctx.match_knn2_ratio(q, t, ratio)
+    eidx, edist = O.match_knn2(q, t)
+    assert np.array_equal(idx, eidx)
+    assert np.array_equal(dist, edist)
+    eps = O.ratio_test(eidx, edist, ratio if ratio is not None else 1.0, enabled=ratio is not None)
+    assert np.array_equal(ps, eps)
+
+
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (5, 1), (1, 7), (257, 513), (2000, 3)])
+@pytest.mark.parametrize("ratio", [0.75, 0.85, None])
+def test_random_descriptors(ctx, nq, nt, ratio):
+    rng = np.random.default_rng(nq * 131 + nt)
+    _check(ctx, rng.integers(0, 256, (nq, 32), dtype=np.uint8), rng.integers(0, 256, (nt, 32), dtype=np.uint8), ratio)
+
+
+def test_ties_and_duplicates(ctx):
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    t = np.concatenate([base, base, base[::-1]])  # every train descriptor appears 3 times -> distance ties
+    q = base.copy()
+    q[:, 0] ^= 1
+    _check(ctx, q, t, 0.75)
+    _check(ctx, np.zeros((10, 32), np.uint8), np.zeros((10, 32), np.uint8), 0.75)
+    _check(ctx, np.zeros((3, 32), np.uint8), np.full((4, 32), 255, np.uint8), None)  # distance 256
+
+
+def test_self_match_config2(ctx):
+    """BASELINE config 2: 2000-descriptor self match -> best is self at distance 0."""
+    rng = np.random.default_rng(2)
+    d = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+    idx, dist, ps = ctx.match_knn2_ratio(d, d, 0.75)
+    assert np.array_equal(idx[:, 0], np.arange(2000)) and (dist[:, 0] == 0).all() and ps.all()
+    _check(ctx, d, d, 0.75)
+
+
+def test_batched(ctx):
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 256, (3, 300, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (3, 200, 32), dtype=np.uint8)
+    idx, dist, ps = ctx.match_knn2_ratio(q, t, 0.8)
+    for b in range(3):
+        i1, d1, p1 = ctx.match_knn2_ratio(q[b], t[b], 0.8)
+        assert np.array_equal(idx[b], i1) and np.array_equal(dist[b], d1) and np.array_equal(ps[b], p1)

@@ -1,0 +1,163 @@
+"""GPU parity of the ORB extractor stages: HIP path through the C-ABI vs the CPU oracle, bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import greedy_min_dist, gt_pair, load_png_bgr, synthetic_frame
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import vslam_amd as V
+    c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=8)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import orb_oracle
+    return orb_oracle
+
+
+def _prm(V, O, order, **kw):
+    p = V.orb_params(select_order=order, **kw)
+    o = O.params(**kw)
+    return p, o
+
+
+@pytest.mark.parametrize("size", [(640, 480), (478, 850), (333, 257)])
+def test_pyramid_and_blur_levels(ctx, O, size):
+    import vslam_amd as V
+    w, h = size
+    img = synthetic_frame(7, w, h)
+    p, o = _prm(V, O, V.ORDER_LIBSTDCXX)
+    lw, lh, _, _ = O.levels(w, h, o)
+    for L in range(8):
+        got = ctx.dbg_pyramid_level(img, p, L)
+        exp = O.pyramid_level(img, o, L)
+        assert got.shape == exp.shape == (lh[L], lw[L])
+        assert np.array_equal(got, exp), "raw level %d" % L
+        gotb = ctx.dbg_pyramid_level(img, p, L, blurred=True)
+        expb = O.pyramid_level(img, o, L, blurred=True)
+        assert np.array_equal(gotb, expb), "blurred level %d" % L
+
+
+@pytest.mark.parametrize("thr", [7, 20])
+def test_fast_nms_candidates(ctx, O, thr):
+    import vslam_amd as V
+    img = synthetic_frame(11)
+    p, o = _prm(V, O, V.ORDER_LIBSTDCXX, fast_threshold=thr)
+    lw, lh, _, _ = O.levels(640, 480, o)
+    for L in range(8):
+        lvl = O.pyramid_level(img, o, L)
+        f = O.fast_level(lvl, thr)
+        f = f[(f[:, 0] >= 31) & (f[:, 0] < lw[L] - 31) & (f[:, 1] >= 31) & (f[:, 1] < lh[L] - 31)]
+        got = ctx.dbg_fast_level(img, p, L)
+        assert len(got) == len(f), "level %d count" % L
+        assert np.array_equal(got, f), "level %d raster-ordered (x, y, score)" % L
+
+
+def _retain_cases():
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in (1, 2, 3, 4, 7, 31, 32, 33, 34, 40, 41, 42, 64, 100, 257, 1000, 5000, 20000):
+        for kind in ("float", "ties", "sorted", "rsorted", "const"):
+            if kind == "float": r = rng.normal(size=n).astype(np.float32)
+            elif kind == "ties": r = rng.integers(0, 12, size=n).astype(np.float32)
+            elif kind == "sorted": r = np.sort(rng.normal(size=n)).astype(np.float32)
+            elif kind == "rsorted": r = np.sort(rng.normal(size=n))[::-1].astype(np.float32)
+            else: r = np.full(n, 3.0, np.float32)
+            for k in sorted({0, 1, 2, n // 3, n // 2, n - 1, n, n + 5}):
+                cases.append((r, k))
+    # median-of-3 killer: drives libstdc++ introselect into its heap-select fallback
+    n = 4096
+    a = np.zeros(n, np.float32)
+    k = n // 2
+    for i in range(1, k + 1):
+        if i & 1:
+            a[i - 1] = i; a[i] = k + i
+        a[k + i - 1] = 2 * i
+    cases.append((-a, n // 2)); cases.append((a, n // 2)); cases.append((a, 10))
+    return cases
+
+
+def test_retain_best_replay_both_orders(ctx, O):
+    import vslam_amd as V
+    for order in (V.ORDER_LIBSTDCXX, V.ORDER_MSVC):
+        O.lib().orc_set_variant(order, 0)
+        for r, k in _retain_cases():
+            exp = O.retain_best(r, k)
+            got = ctx.dbg_retain_best(r, k, order)
+            assert np.array_equal(got, exp), "order %d n %d k %d" % (order, len(r), k)
+    O.lib().orc_set_variant(1, 0)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("nfeat,thr", [(2000, 7), (500, 20), (200, 20)])
+def test_detect_and_compute_bit_exact(ctx, O, order, nfeat, thr):
+    import vslam_amd as V
+    O.lib().orc_set_variant(order, 0)
+    p, o = _prm(V, O, order, nfeatures=nfeat, fast_threshold=thr)
+    for seed in (20250523, 20250524):
+        img = synthetic_frame(seed)
+        (kps, desc), = ctx.orb_detect_compute(img, p)
+        ek, ed = O.detect_and_compute(img, o)
+        assert len(kps) == len(ek)
+        for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(kps[f], ek[f]), f
+        assert np.array_equal(desc, ed)
+    O.lib().orc_set_variant(1, 0)
+
+
+def test_detector_kat_through_the_c_abi(ctx):
+    """The reference's 40 known-answer keypoint lists, reproduced by the HIP path itself (BGR input, MSVC order)."""
+    import vslam_amd as V
+    p = V.orb_params(nfeatures=200, fast_threshold=20, select_order=V.ORDER_MSVC)
+    for pair in range(1, 21):
+        d, gt = gt_pair(pair)
+        for k in (1, 2):
+            bgr = load_png_bgr(os.path.join(d, "img%d.png" % k))
+            (kps, _), = ctx.orb_detect_compute(bgr, p, want_desc=False)
+            got = greedy_min_dist([(float(a["x"]), float(a["y"])) for a in kps])
+            assert got == [tuple(q) for q in gt["keypoints%d" % k]], "pair %d img %d" % (pair, k)
+
+
+def test_batch_equals_single(ctx):
+    import vslam_amd as V
+    p = V.orb_params(nfeatures=1000)
+    imgs = np.stack([synthetic_frame(100 + i) for i in range(5)])
+    res = ctx.orb_detect_compute(imgs, p)
+    for i in range(5):
+        (k1, d1), = ctx.orb_detect_compute(imgs[i], p)
+        assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1)
+
+
+def test_compute_given_keypoints(ctx, O):
+    """orb.compute at caller keypoints: border drop, angle as supplied (-1), octave honoured, unsorted regroup."""
+    import vslam_amd as V
+    img = synthetic_frame(3)
+    p, o = _prm(V, O, V.ORDER_LIBSTDCXX)
+    rng = np.random.default_rng(1)
+    n = 300
+    k = np.zeros(n, V.KP_DTYPE)
+    k["x"] = rng.uniform(0, 640, n).astype(np.float32); k["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    k["size"] = 31; k["angle"] = -1; k["class_id"] = -1
+    kept, desc = ctx.orb_compute(img, p, k)
+    ekept, edesc = O.compute(img, o, k)
+    assert np.array_equal(kept, ekept) and np.array_equal(desc, edesc)
+    assert len(kept) < n  # some were inside the 31-px border band
+    k["octave"] = rng.integers(0, 4, n); k["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kept, desc = ctx.orb_compute(img, p, k)
+    ekept, edesc = O.compute(img, o, k)
+    assert np.array_equal(kept, ekept) and np.array_equal(desc, edesc)
+
+
+def test_no_keypoints_on_flat_image(ctx):
+    import vslam_amd as V
+    p = V.orb_params()
+    (kps, desc), = ctx.orb_detect_compute(np.full((480, 640), 128, np.uint8), p)
+    assert len(kps) == 0 and desc is None

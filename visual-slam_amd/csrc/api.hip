@@ -1,0 +1,410 @@
+// api.hip -- extern "C" entry points declared in include/vslam_amd.h.
+// Host entry points stage their inputs into HBM, run the same device pipeline the batched mode uses, and
+// copy the results back; there is no CPU implementation behind any of them.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+static int check_flags(mo_ctx* c) {
+    int f[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(f, c->d_flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (f[0] & 1) return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)");
+    if (f[0] & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
+    return MO_OK;
+}
+
+// device pipeline on frames already resident as dense gray [batch][h][w]
+static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int w, int h, int batch,
+                       mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts, bool fresh_timing) {
+    int rc = mo_build_plan(c, p, w, h, batch);
+    if (rc) return rc;
+    if (cap < 1) return mo_fail(c, MO_ERR_ARG, "cap must be >= 1");
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    if (fresh_timing) mo_stage_begin(c);
+    if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels))) return rc;
+    mo_stage_mark(c, "pyramid");
+    if ((rc = orb_launch_fast(c, d_gray, batch))) return rc;
+    mo_stage_mark(c, "fast_nms");
+    if ((rc = orb_launch_select(c, d_gray, batch))) return rc;
+    mo_stage_mark(c, "select_harris");
+    if (d_desc) {
+        if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels))) return rc;
+        mo_stage_mark(c, "blur");
+    }
+    if ((rc = orb_launch_describe(c, d_gray, batch, d_kps, d_desc, cap, d_counts))) return rc;
+    mo_stage_mark(c, "angle_rbrief");
+    return MO_OK;
+}
+
+// copy host images (any stride / 1 or 3 channels) into a dense device gray batch; returns the device pointer
+static int stage_images(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int ch, int batch, const uint8_t** d_gray) {
+    if (!img) return mo_fail(c, MO_ERR_ARG, "img is NULL");
+    if (ch != 1 && ch != 3) return mo_fail(c, MO_ERR_ARG, "ch must be 1 (gray) or 3 (BGR)");
+    if (stride < w * ch) return mo_fail(c, MO_ERR_ARG, "stride smaller than a row");
+    size_t row = (size_t)w * ch, frame = row * h;
+    int rc = mo_reserve(c, c->d_in, c->d_in_bytes, frame * batch);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy2DAsync(c->d_in, row, img, (size_t)stride, row, (size_t)h * batch, hipMemcpyHostToDevice, c->stream));
+    if (ch == 3) {
+        rc = mo_reserve(c, c->d_gray, c->d_gray_bytes, (size_t)w * h * batch);
+        if (rc) return rc;
+        if ((rc = orb_launch_gray(c, c->d_in, w, h, batch, c->d_gray))) return rc;
+        *d_gray = c->d_gray;
+    } else {
+        *d_gray = c->d_in;
+    }
+    return MO_OK;
+}
+
+static int reserve_out(mo_ctx* c, int batch, int cap) {
+    if (c->d_kps && c->out_cap >= cap && c->out_batch >= batch) return MO_OK;
+    if (c->d_kps) { hipFree(c->d_kps); hipFree(c->d_desc); hipFree(c->d_counts); c->d_kps = nullptr; }
+    size_t n = (size_t)batch * cap;
+    HIPCHK(c, hipMalloc((void**)&c->d_kps, n * sizeof(mo_keypoint)));
+    HIPCHK(c, hipMalloc((void**)&c->d_desc, n * 32));
+    HIPCHK(c, hipMalloc((void**)&c->d_counts, (size_t)batch * sizeof(int)));
+    c->out_cap = cap; c->out_batch = batch;
+    return MO_OK;
+}
+
+extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
+                                     int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts) {
+    if (!c) return MO_ERR_ARG;
+    if (!kps || !counts) return mo_fail(c, MO_ERR_ARG, "kps/counts is NULL");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint8_t* d_gray = nullptr;
+    int rc = mo_build_plan(c, p, w, h, batch);  // validates sizes before any staging
+    if (rc) return rc;
+    if ((rc = stage_images(c, img, w, h, stride, ch, batch, &d_gray))) return rc;
+    if ((rc = reserve_out(c, batch, cap))) return rc;
+    if ((rc = run_extract(c, p, d_gray, w, h, batch, c->d_kps, desc ? c->d_desc : nullptr, cap, c->d_counts, true))) return rc;
+    HIPCHK(c, hipMemcpyAsync(counts, c->d_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    rc = check_flags(c);
+    if (rc && rc != MO_ERR_CAPACITY) return rc;
+    if (rc == MO_ERR_CAPACITY) {
+        bool user_cap = false;
+        for (int f = 0; f < batch; f++) user_cap |= counts[f] > cap;
+        if (!user_cap) return rc;  // internal capacity
+        return rc;
+    }
+    for (int f = 0; f < batch; f++) {
+        int n = std::min(counts[f], cap);
+        if (n <= 0) continue;
+        HIPCHK(c, hipMemcpyAsync(kps + (size_t)f * cap, c->d_kps + (size_t)f * cap, (size_t)n * sizeof(mo_keypoint),
+                                 hipMemcpyDeviceToHost, c->stream));
+        if (desc)
+            HIPCHK(c, hipMemcpyAsync(desc + (size_t)f * cap * 32, c->d_desc + (size_t)f * cap * 32, (size_t)n * 32,
+                                     hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MO_OK;
+}
+
+extern "C" int mo_orb_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
+                              const mo_keypoint* kps_in, int n_in, int32_t* kept_idx, uint8_t* desc, int* n_out) {
+    if (!c) return MO_ERR_ARG;
+    if (!p || !n_out || (n_in > 0 && (!kps_in || !kept_idx || !desc))) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_out = 0;
+    // host-side list logic of Feature2D::compute / ORB_Impl::detectAndCompute(useProvidedKeypoints):
+    // level count from the octaves, border filter on the full image, regroup by octave when unsorted
+    int nlevels = 0;
+    bool sorted = true;
+    for (int i = 0; i < n_in; i++) {
+        int L = kps_in[i].octave;
+        if (L < 0) return mo_fail(c, MO_ERR_ARG, "keypoint octave < 0");
+        if (i > 0 && L < kps_in[i - 1].octave) sorted = false;
+        nlevels = std::max(nlevels, L);
+    }
+    nlevels++;
+    if (nlevels > MO_MAX_LEVELS) return mo_fail(c, MO_ERR_UNSUPPORTED, "keypoint octave >= 12");
+    std::vector<int> keep;
+    int et = p->edge_threshold;
+    if (!(et > 0 && (h <= et * 2 || w <= et * 2))) {
+        for (int i = 0; i < n_in; i++) {
+            int x = (int)lrintf(kps_in[i].x), y = (int)lrintf(kps_in[i].y);
+            if (et > 0 && !(x >= et && x < w - et && y >= et && y < h - et)) continue;
+            keep.push_back(i);
+        }
+    }
+    if (!sorted) {
+        std::vector<int> re;
+        for (int L = 0; L < nlevels; L++)
+            for (int i : keep)
+                if (kps_in[i].octave == L) re.push_back(i);
+        keep.swap(re);
+    }
+    int n = (int)keep.size();
+    for (int i = 0; i < n; i++) kept_idx[i] = keep[i];
+    *n_out = n;
+    if (n == 0) return MO_OK;
+    mo_orb_params pp = *p;
+    if (nlevels > pp.nlevels) pp.nlevels = nlevels;
+    int rc = mo_build_plan(c, &pp, w, h, 1);
+    if (rc) return rc;
+    const uint8_t* d_gray = nullptr;
+    if ((rc = stage_images(c, img, w, h, stride, ch, 1, &d_gray))) return rc;
+    std::vector<mo_keypoint> kk(n);
+    for (int i = 0; i < n; i++) kk[i] = kps_in[keep[i]];
+    size_t kb = (size_t)n * sizeof(mo_keypoint);
+    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, kb + (size_t)n * 32))) return rc;
+    mo_keypoint* d_k = (mo_keypoint*)c->d_tmp;
+    uint8_t* d_d = (uint8_t*)c->d_tmp + kb;
+    HIPCHK(c, hipMemcpyAsync(d_k, kk.data(), kb, hipMemcpyHostToDevice, c->stream));
+    mo_stage_begin(c);
+    if ((rc = orb_launch_pyramid(c, d_gray, 1, nlevels))) return rc;
+    if ((rc = orb_launch_blur(c, d_gray, 1, nlevels))) return rc;
+    if ((rc = orb_launch_describe_given(c, d_gray, d_k, n, d_d))) return rc;
+    mo_stage_mark(c, "compute");
+    HIPCHK(c, hipMemcpyAsync(desc, d_d, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MO_OK;
+}
+
+extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, const double* ratio,
+                                   int batch, int32_t* train_idx, int32_t* dist, uint8_t* pass) {
+    if (!c) return MO_ERR_ARG;
+    if (nq < 0 || nt < 0 || batch < 1) return mo_fail(c, MO_ERR_ARG, "bad sizes");
+    if (nq == 0) return MO_OK;
+    if (!q || !train_idx || !dist || !pass || (nt > 0 && !t)) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t qb = (size_t)batch * nq * 32, tb = (size_t)batch * std::max(nt, 1) * 32, n = (size_t)batch * nq;
+    int rc;
+    if ((rc = mo_reserve(c, c->d_mq, c->m_q_bytes, qb))) return rc;
+    if ((rc = mo_reserve(c, c->d_mt, c->m_t_bytes, tb))) return rc;
+    if (n > c->m_n) {
+        if (c->d_midx) { hipFree(c->d_midx); hipFree(c->d_mdist); hipFree(c->d_mpass); }
+        HIPCHK(c, hipMalloc((void**)&c->d_midx, n * 2 * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_mdist, n * 2 * sizeof(int32_t)));
+        HIPCHK(c, hipMalloc((void**)&c->d_mpass, n));
+        c->m_n = n;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_mq, q, qb, hipMemcpyHostToDevice, c->stream));
+    if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, t, (size_t)batch * nt * 32, hipMemcpyHostToDevice, c->stream));
+    mo_stage_begin(c);
+    rc = match_launch_pairs(c, c->d_mq, c->d_mt, (size_t)nq * 32, (size_t)nt * 32, nullptr, nullptr, nullptr, nq, nt, batch,
+                            nq, ratio ? *ratio : 0.0, c->d_midx, c->d_mdist, c->d_mpass);
+    if (rc) return rc;
+    mo_stage_mark(c, "match_knn2_ratio");
+    HIPCHK(c, hipMemcpyAsync(train_idx, c->d_midx, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dist, c->d_mdist, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pass, c->d_mpass, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MO_OK;
+}
+
+extern "C" int mo_init_two_view(mo_ctx* c, const float* p1, const float* p2, int m, const double K[9], double thr_px,
+                                double prob, int n_hyp, uint64_t seed, double R[9], double t[3], double E[9],
+                                uint8_t* ransac_inlier, uint8_t* inlier, float* X, int* n_good) {
+    (void)prob;
+    if (!c) return MO_ERR_ARG;
+    if (!p1 || !p2 || !K || !R || !t || !inlier || !X || !n_good) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    if (m < 0 || m > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "m must be 0..4096");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_good = 0;
+    if (m < 8) {
+        for (int i = 0; i < 9; i++) R[i] = NAN;
+        for (int i = 0; i < 3; i++) t[i] = NAN;
+        std::memset(inlier, 0, (size_t)m);
+        if (ransac_inlier) std::memset(ransac_inlier, 0, (size_t)m);
+        if (E) for (int i = 0; i < 9; i++) E[i] = NAN;
+        for (int i = 0; i < 3 * m; i++) X[i] = NAN;
+        return MO_OK;
+    }
+    size_t pb = (size_t)m * 2 * sizeof(float);
+    size_t need = 2 * pb + 12 * sizeof(double) + 9 * sizeof(double) + (size_t)m * 3 * sizeof(float) + 2 * (size_t)m + 64;
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, need + 256);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    double* d_pose = (double*)b; b += 12 * sizeof(double);
+    double* d_E = (double*)b; b += 9 * sizeof(double);
+    int32_t* d_n = (int32_t*)b; b += 8;
+    float* d_p1 = (float*)b; b += pb;
+    float* d_p2 = (float*)b; b += pb;
+    float* d_X = (float*)b; b += (size_t)m * 3 * sizeof(float);
+    uint8_t* d_inl = b; b += m;
+    uint8_t* d_ran = b;
+    HIPCHK(c, hipMemcpyAsync(d_p1, p1, pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_p2, p2, pb, hipMemcpyHostToDevice, c->stream));
+    TwoViewArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_pairs = 1; a.cap = m; a.n_hyp = n_hyp;
+    for (int i = 0; i < 9; i++) a.K[i] = K[i];
+    a.thr_px = thr_px; a.seed = seed;
+    a.d_p1 = d_p1; a.d_p2 = d_p2; a.m_fixed = m;
+    a.d_pose = d_pose; a.d_E = d_E; a.d_points = d_X; a.d_inlier = d_inl; a.d_ransac = d_ran; a.d_n_points = d_n;
+    mo_stage_begin(c);
+    if ((rc = twoview_launch(c, a))) return rc;
+    mo_stage_mark(c, "two_view");
+    double pose[12];
+    int32_t ng = 0;
+    HIPCHK(c, hipMemcpyAsync(pose, d_pose, sizeof(pose), hipMemcpyDeviceToHost, c->stream));
+    if (E) HIPCHK(c, hipMemcpyAsync(E, d_E, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ng, d_n, sizeof(ng), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(X, d_X, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(inlier, d_inl, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (ransac_inlier) HIPCHK(c, hipMemcpyAsync(ransac_inlier, d_ran, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 9; i++) R[i] = pose[i];
+    for (int i = 0; i < 3; i++) t[i] = pose[9 + i];
+    *n_good = ng;
+    return MO_OK;
+}
+
+extern "C" int mo_triangulate_points(mo_ctx* c, const double P1[12], const double P2[12], const float* p1, const float* p2,
+                                     int n, float* X4) {
+    if (!c) return MO_ERR_ARG;
+    if (n < 0 || !P1 || !P2 || (n > 0 && (!p1 || !p2 || !X4))) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    if (n == 0) return MO_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t pb = (size_t)n * 2 * sizeof(float);
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, 2 * pb + (size_t)n * 4 * sizeof(float) + 64);
+    if (rc) return rc;
+    float* d_p1 = (float*)c->d_tmp;
+    float* d_p2 = d_p1 + (size_t)n * 2;
+    float* d_X = d_p2 + (size_t)n * 2;
+    HIPCHK(c, hipMemcpyAsync(d_p1, p1, pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_p2, p2, pb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = triangulate_launch(c, P1, P2, d_p1, d_p2, n, d_X))) return rc;
+    HIPCHK(c, hipMemcpyAsync(X4, d_X, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MO_OK;
+}
+
+// ---- device-resident batched mode -----------------------------------------------------------------
+extern "C" int mo_dev_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int w, int h, int batch,
+                                         mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts) {
+    if (!c) return MO_ERR_ARG;
+    if (!d_gray || !d_kps || !d_counts) return mo_fail(c, MO_ERR_ARG, "NULL device pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_extract(c, p, d_gray, w, h, batch, d_kps, d_desc, cap, d_counts, true);
+}
+
+extern "C" int mo_dev_match_pairs(mo_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int cap, const int32_t* d_qf,
+                                  const int32_t* d_tf, int n_pairs, double ratio, int32_t* d_idx, int32_t* d_dist,
+                                  uint8_t* d_pass) {
+    if (!c) return MO_ERR_ARG;
+    if (!d_desc || !d_counts || !d_idx || !d_dist || !d_pass) return mo_fail(c, MO_ERR_ARG, "NULL device pointer");
+    HIPCHK(c, hipSetDevice(c->device));
+    mo_stage_begin(c);
+    int rc = match_launch_pairs(c, d_desc, d_desc, (size_t)cap * 32, (size_t)cap * 32, d_counts, d_qf, d_tf, 0, 0, n_pairs, cap,
+                                ratio, d_idx, d_dist, d_pass);
+    mo_stage_mark(c, "match_knn2_ratio");
+    return rc;
+}
+
+__global__ void k_pair_frames(int32_t* qf, int32_t* tf, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { qf[i] = i; tf[i] = i + 1; }
+}
+
+extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo_batch_io* io) {
+    if (!c) return MO_ERR_ARG;
+    if (!io || !io->d_gray || !io->d_kps || !io->d_desc || !io->d_counts) return mo_fail(c, MO_ERR_ARG, "NULL in mo_batch_io");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, true);
+    if (rc) return rc;
+    int n_pairs = io->batch - 1;
+    if (n_pairs < 1 || !io->d_match_idx) return MO_OK;
+    if (!io->d_match_dist || !io->d_match_pass) return mo_fail(c, MO_ERR_ARG, "match outputs missing");
+    size_t need = (size_t)n_pairs * 2 * sizeof(int32_t);
+    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, need))) return rc;
+    int32_t* qf = (int32_t*)c->d_tmp;
+    int32_t* tf = qf + n_pairs;
+    hipLaunchKernelGGL(k_pair_frames, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, qf, tf, n_pairs);
+    rc = match_launch_pairs(c, io->d_desc, io->d_desc, (size_t)io->cap * 32, (size_t)io->cap * 32, io->d_counts, qf, tf, 0, 0,
+                            n_pairs, io->cap, io->ratio, io->d_match_idx, io->d_match_dist, io->d_match_pass);
+    if (rc) return rc;
+    mo_stage_mark(c, "match_knn2_ratio");
+    if (io->n_hyp > 0) {
+        if (!io->d_points || !io->d_n_points) return mo_fail(c, MO_ERR_ARG, "two-view outputs missing");
+        TwoViewArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n_pairs = n_pairs; a.cap = io->cap; a.n_hyp = io->n_hyp;
+        for (int i = 0; i < 9; i++) a.K[i] = io->K[i];
+        a.thr_px = io->thr_px; a.seed = io->seed;
+        a.d_kps = io->d_kps; a.d_counts = io->d_counts; a.d_match_idx = io->d_match_idx; a.d_match_pass = io->d_match_pass;
+        a.d_pose = io->d_pose; a.d_points = io->d_points; a.d_n_points = io->d_n_points;
+        if ((rc = twoview_launch(c, a))) return rc;
+        mo_stage_mark(c, "two_view");
+    }
+    return MO_OK;
+}
+
+// ---- probes for stage-level parity tests -------------------------------------------------------------
+extern "C" int mo_dbg_pyramid_level(mo_ctx* c, const mo_orb_params* p, const uint8_t* gray, int w, int h, int level,
+                                    int blurred, uint8_t* out, int* lw, int* lh) {
+    if (!c) return MO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = mo_build_plan(c, p, w, h, 1);
+    if (rc) return rc;
+    if (level < 0 || level >= c->plan.nlevels) return mo_fail(c, MO_ERR_ARG, "level out of range");
+    const uint8_t* d_gray = nullptr;
+    if ((rc = stage_images(c, gray, w, h, w, 1, 1, &d_gray))) return rc;
+    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels))) return rc;
+    const LevelInfo& v = c->plan.lv[level];
+    *lw = v.w; *lh = v.h;
+    if (blurred) {
+        if ((rc = orb_launch_blur(c, d_gray, 1, c->plan.nlevels))) return rc;
+        HIPCHK(c, hipMemcpy2DAsync(out, v.w, c->d_blur + v.boff, v.bpitch, v.w, v.h, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        const uint8_t* src = level == 0 ? d_gray : c->d_pyr + v.off;
+        HIPCHK(c, hipMemcpy2DAsync(out, v.w, src, v.pitch, v.w, v.h, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MO_OK;
+}
+
+extern "C" int mo_dbg_fast_level(mo_ctx* c, const mo_orb_params* p, const uint8_t* gray, int w, int h, int level,
+                                 int32_t* xys, int cap, int* n) {
+    if (!c) return MO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = mo_build_plan(c, p, w, h, 1);
+    if (rc) return rc;
+    if (level < 0 || level >= c->plan.nlevels) return mo_fail(c, MO_ERR_ARG, "level out of range");
+    const uint8_t* d_gray = nullptr;
+    if ((rc = stage_images(c, gray, w, h, w, 1, 1, &d_gray))) return rc;
+    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels))) return rc;
+    if ((rc = orb_launch_fast(c, d_gray, 1))) return rc;
+    const LevelInfo& v = c->plan.lv[level];
+    std::vector<int> cnt(std::max(v.nstrips, 1));
+    std::vector<uint32_t> ent((size_t)std::max(v.cand_cap, 1));
+    if (v.nstrips > 0) {
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), c->d_strip_cnt + v.strip_base, v.nstrips * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(ent.data(), c->d_cand + v.cand_off, (size_t)v.cand_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int k = 0;
+    for (int s = 0; s < v.nstrips; s++)
+        for (int i = 0; i < cnt[s]; i++) {
+            uint32_t e = ent[(size_t)s * v.strip_cap + i];
+            if (k < cap) { xys[3 * k] = e & 0xFFF; xys[3 * k + 1] = (e >> 12) & 0xFFF; xys[3 * k + 2] = e >> 24; }
+            k++;
+        }
+    *n = k;
+    return MO_OK;
+}
+
+extern "C" int mo_dbg_retain_best(mo_ctx* c, const float* resp, int n, int n_points, int select_order, int32_t* order,
+                                  int* n_out) {
+    if (!c) return MO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n <= 0) { *n_out = 0; return MO_OK; }
+    float* d_r = nullptr; int32_t* d_o = nullptr; int* d_n = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_r, (size_t)n * sizeof(float)));
+    HIPCHK(c, hipMalloc((void**)&d_o, (size_t)n * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void**)&d_n, sizeof(int)));
+    HIPCHK(c, hipMemcpyAsync(d_r, resp, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    int rc = orb_launch_retain_probe(c, d_r, n, n_points, select_order, d_o, d_n);
+    if (!rc) {
+        HIPCHK(c, hipMemcpyAsync(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(order, d_o, (size_t)(*n_out) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    hipFree(d_r); hipFree(d_o); hipFree(d_n);
+    return rc;
+}

@@ -1,0 +1,156 @@
+// common.h -- context, plan and helpers shared by the HIP translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vslam_amd.h"
+
+#define MO_MAX_LEVELS 12
+#define MO_HALF_PATCH 15
+#define MO_STRIP_ROWS 8
+
+// per-level geometry, uploaded by value as a kernel argument
+struct LevelInfo {
+    int w, h, pitch;      // level size and row pitch in bytes (level 0: pitch = w, aliases the input)
+    int off;              // byte offset of the level inside one frame's raw pyramid slab (level 0: unused)
+    int bpitch, boff;     // row pitch / byte offset inside one frame's blurred pyramid slab
+    float scale;          // (float)pow((double)scale_factor, L)
+    int quota;            // features wanted on this level
+    int bx0, by0, bw, bh; // border region [bx0, bx0+bw) x [by0, by0+bh): keypoints allowed here
+    int strip_rows;       // rows per FAST strip
+    int nstrips;          // strips covering the border region
+    int strip_cap;        // entries per strip slot
+    int strip_base;       // index of this level's first strip among one frame's strips
+    int cand_off;         // entry offset of this level's first strip slot in one frame's candidate slab
+    int cand_cap;         // total candidate capacity of the level (nstrips * strip_cap)
+    int fin_off, fin_cap; // final-keypoint slot of the level in one frame's slab
+    int scr_off;          // u64 offset of the level's overflow scratch inside one frame's scratch slab
+};
+
+struct Plan {
+    int w, h, nlevels;
+    int edge_threshold, fast_threshold, select_order, nfeatures;
+    int pyr_stride;      // bytes per frame of the raw pyramid slab (levels 1..n-1)
+    int blur_stride;     // bytes per frame of the blurred pyramid slab (levels 0..n-1)
+    int strips_per_frame;
+    int cand_stride;     // candidate entries (u32) per frame
+    int fin_stride;      // final entries per frame
+    int umax[MO_HALF_PATCH + 1];
+    int gk[7];           // 7-tap Gaussian, 8 fractional bits
+    LevelInfo lv[MO_MAX_LEVELS];
+};
+
+struct FinalKp {  // 8 bytes: survivor of both retainBest passes, level coordinates
+    uint16_t x, y;
+    float response;
+};
+
+struct ResizeTab {  // device arrays of one level's INTER_LINEAR_EXACT coefficients
+    int* xofs = nullptr; int* xc1 = nullptr; int* yofs = nullptr; int* yc1 = nullptr;
+};
+
+#define MO_NSTAGES 16
+
+struct mo_ctx {
+    int device = 0;
+    int max_w = 0, max_h = 0, max_batch = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // plan (rebuilt when w, h or the ORB parameters change)
+    bool plan_valid = false;
+    mo_orb_params plan_params{};
+    Plan plan{};
+    ResizeTab rtab[MO_MAX_LEVELS];
+    int batch_alloc = 0;  // frames the work buffers below are sized for
+
+    // work buffers (device)
+    uint8_t* d_in = nullptr;       size_t d_in_bytes = 0;      // staged host images (any ch)
+    uint8_t* d_gray = nullptr;     size_t d_gray_bytes = 0;    // gray level 0 when converted / staged
+    uint8_t* d_pyr = nullptr;      // [batch][pyr_stride]
+    uint8_t* d_blur = nullptr;     // [batch][blur_stride]
+    uint32_t* d_cand = nullptr;    // [batch][cand_stride]
+    int* d_strip_cnt = nullptr;    // [batch][strips_per_frame]
+    uint64_t* d_scratch = nullptr; // [batch][nlevels] overflow scratch for the selection replay
+    size_t scratch_stride = 0;     // u64 entries per frame of overflow scratch
+    FinalKp* d_fin = nullptr;      // [batch][fin_stride]
+    int* d_fin_cnt = nullptr;      // [batch][MO_MAX_LEVELS]
+    int* d_flags = nullptr;        // [4] error flags raised by kernels
+    // output staging for the host API
+    mo_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int* d_counts = nullptr; int out_cap = 0, out_batch = 0;
+    // matcher staging
+    uint8_t* d_mq = nullptr; uint8_t* d_mt = nullptr; int32_t* d_midx = nullptr; int32_t* d_mdist = nullptr;
+    uint8_t* d_mpass = nullptr; size_t m_q_bytes = 0, m_t_bytes = 0, m_n = 0;
+    // two-view work buffers
+    void* d_tv = nullptr; size_t tv_bytes = 0;
+    // generic temp
+    void* d_tmp = nullptr; size_t tmp_bytes = 0;
+
+    // stage timing
+    hipEvent_t ev[MO_NSTAGES + 1] = {};
+    const char* stage_names[MO_NSTAGES + 1] = {};
+    int n_stages = 0;
+    bool timing = true;
+};
+
+int mo_fail(mo_ctx* c, int code, const std::string& msg);
+
+#define HIPCHK(c, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (expr);                                                                     \
+        if (e__ != hipSuccess)                                                                       \
+            return mo_fail((c), MO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+// grow-only device buffer helper
+template <class T> int mo_reserve(mo_ctx* c, T*& p, size_t& have_bytes, size_t need_bytes) {
+    if (need_bytes <= have_bytes && p) return MO_OK;
+    if (p) HIPCHK(c, hipFree(p));
+    p = nullptr; have_bytes = 0;
+    HIPCHK(c, hipMalloc((void**)&p, need_bytes ? need_bytes : 16));
+    have_bytes = need_bytes;
+    return MO_OK;
+}
+
+// stage timing helpers (hipEvents on the context stream)
+void mo_stage_begin(mo_ctx* c);
+void mo_stage_mark(mo_ctx* c, const char* name);
+
+// orb_plan.cpp-equivalent host logic (ctx.hip)
+int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch);
+
+// kernel launchers (orb_kernels.hip)
+int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray);
+int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
+int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
+int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch);
+int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch);
+int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
+                        int* d_counts);
+int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc);
+int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order,
+                            int* d_nout);
+// match_kernels.hip
+int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t q_stride, size_t t_stride,
+                       const int32_t* d_counts, const int32_t* d_qf, const int32_t* d_tf, int nq_fixed, int nt_fixed,
+                       int n_pairs, int out_stride, double ratio, int32_t* d_idx, int32_t* d_dist, uint8_t* d_pass);
+// twoview_kernels.hip
+struct TwoViewArgs {
+    int n_pairs, cap, n_hyp;
+    double K[9], thr_px;
+    uint64_t seed;
+    // per pair: matches are read from the matcher outputs + keypoints, or from explicit point arrays
+    const mo_keypoint* d_kps; const int32_t* d_counts; const int32_t* d_match_idx; const uint8_t* d_match_pass;
+    const float* d_p1; const float* d_p2; int m_fixed;  // explicit points (host API): [m][2]
+    double* d_pose;   // [pairs][12]
+    double* d_E;      // [pairs][9] or null
+    float* d_points;  // [pairs][cap][3]
+    uint8_t* d_inlier; // [pairs][cap] pose mask
+    uint8_t* d_ransac; // [pairs][cap] RANSAC (Sampson) mask or null
+    int32_t* d_n_points; // [pairs]
+};
+int twoview_launch(mo_ctx* c, const TwoViewArgs& a);
+size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp);
+int triangulate_launch(mo_ctx* c, const double* P1, const double* P2, const float* d_p1, const float* d_p2, int n, float* d_X4);

@@ -1,0 +1,606 @@
+// orb_kernels.hip -- hand-written gfx950 kernels of the ORB extractor (replaces cv2.ORB.detectAndCompute /
+// compute behind src/orbslam2/extractor.py:61-65,79-83 of the reference).
+//
+// Pipeline over a batch of frames (one launch per stage, frames in blockIdx.y):
+//   gray      BGR -> Y, fixed-point 15-bit                                   (only for 3-channel input)
+//   resize    level L from level L-1, INTER_LINEAR_EXACT fixed point          (nlevels-1 dependent launches)
+//   fast      FAST-9/16 score + 3x3 NMS + border filter, full-width strips,   raster-ordered candidate slots
+//             pixel tiles and the score band staged in LDS
+//   select    per (frame, level): retainBest(2q) on FAST score -> Harris -> retainBest(q), exact
+//             standard-library permutation replay (select_replay.h), record arrays in LDS
+//   blur      7x7 Gaussian, 8-bit quantised taps, separable in LDS, REFLECT_101
+//   describe  one wavefront per keypoint: intensity-centroid angle (rows on lanes, DPP-style wave reduce)
+//             + 256 rotated rBRIEF tests (4 per lane)
+// All arithmetic is integer or non-contracted float32 (compile with -ffp-contract=off) so results are
+// bit-identical to the CPU oracle.
+#include "common.h"
+#include "select_replay.h"
+
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+
+#define WAVE 64
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__device__ __forceinline__ const uint8_t* level_ptr(const Plan& P, int L, const uint8_t* gray, const uint8_t* pyr,
+                                                    int frame) {
+    return L == 0 ? gray + (size_t)frame * P.w * P.h : pyr + (size_t)frame * P.pyr_stride + P.lv[L].off;
+}
+
+// ------------------------------------------------------------------ gray ----------------------------
+__global__ void k_gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, size_t npx) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+    gray[i] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15);
+}
+
+int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray) {
+    size_t npx = (size_t)w * h * batch;
+    hipLaunchKernelGGL(k_gray, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, d_bgr, d_gray, npx);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// ------------------------------------------------------------------ resize --------------------------
+__global__ void k_resize(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
+                         uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
+                         const int* __restrict__ xofs, const int* __restrict__ xc1, const int* __restrict__ yofs,
+                         const int* __restrict__ yc1) {
+    int x = blockIdx.x * 64 + threadIdx.x;
+    int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const uint8_t* s = src + (size_t)blockIdx.z * src_fstride;
+    int ox = xofs[x], oy = yofs[y];
+    int ox1 = min(ox + 1, sw - 1), oy1 = min(oy + 1, sh - 1);
+    uint32_t mx1 = xc1[x], mx0 = 256 - mx1, my1 = yc1[y], my0 = 256 - my1;
+    const uint8_t* r0 = s + (size_t)oy * spitch;
+    const uint8_t* r1 = s + (size_t)oy1 * spitch;
+    uint32_t h0 = mx0 * r0[ox] + mx1 * r0[ox1];
+    uint32_t h1 = mx0 * r1[ox] + mx1 * r1[ox1];
+    uint32_t v = my0 * h0 + my1 * h1;
+    dst[(size_t)blockIdx.z * dst_fstride + (size_t)y * dpitch + x] = (uint8_t)((v + 32768u) >> 16);
+}
+
+int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
+    const Plan& P = c->plan;
+    for (int L = 1; L < nlevels; L++) {
+        const LevelInfo& s = P.lv[L - 1];
+        const LevelInfo& d = P.lv[L];
+        const uint8_t* src = L == 1 ? d_gray : c->d_pyr + s.off;
+        size_t sfs = L == 1 ? (size_t)P.w * P.h : (size_t)P.pyr_stride;
+        const ResizeTab& t = c->rtab[L];
+        dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, batch);
+        hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
+                           (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1);
+    }
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// ------------------------------------------------------------------ blur ----------------------------
+struct TileTab {
+    int nlevels;
+    int cum[MO_MAX_LEVELS + 1];  // cumulative tile counts
+    int tx[MO_MAX_LEVELS];       // tiles per row of each level
+};
+
+#define BT_W 64
+#define BT_H 16
+
+__global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* __restrict__ gray,
+                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+    __shared__ uint8_t s_px[(BT_H + 6) * (BT_W + 8)];
+    __shared__ uint16_t s_row[(BT_H + 6) * BT_W];
+    int tile = blockIdx.x, frame = blockIdx.y;
+    int L = 0;
+    while (L + 1 < T.nlevels && tile >= T.cum[L + 1]) L++;
+    tile -= T.cum[L];
+    const LevelInfo lv = P.lv[L];
+    int tx0 = (tile % T.tx[L]) * BT_W, ty0 = (tile / T.tx[L]) * BT_H;
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    const int PW = BT_W + 8;
+    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        int r = i / (BT_W + 6), cidx = i - r * (BT_W + 6);
+        int y = reflect101(ty0 + r - 3, lv.h), x = reflect101(tx0 + cidx - 3, lv.w);
+        s_px[r * PW + cidx] = img[(size_t)y * lv.pitch + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
+        int r = i / BT_W, cidx = i % BT_W;
+        const uint8_t* p = &s_px[r * PW + cidx];
+        int acc = P.gk[0] * p[0] + P.gk[1] * p[1] + P.gk[2] * p[2] + P.gk[3] * p[3] + P.gk[4] * p[4] +
+                  P.gk[5] * p[5] + P.gk[6] * p[6];
+        s_row[i] = (uint16_t)acc;  // <= 257 * 255 = 65535
+    }
+    __syncthreads();
+    uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff;
+    for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
+        int r = i / BT_W, cidx = i % BT_W;
+        int x = tx0 + cidx, y = ty0 + r;
+        if (x >= lv.w || y >= lv.h) continue;
+        const uint16_t* p = &s_row[r * BT_W + cidx];
+        int acc = P.gk[0] * p[0] + P.gk[1] * p[BT_W] + P.gk[2] * p[2 * BT_W] + P.gk[3] * p[3 * BT_W] +
+                  P.gk[4] * p[4 * BT_W] + P.gk[5] * p[5 * BT_W] + P.gk[6] * p[6 * BT_W];
+        int v = (acc + (1 << 15)) >> 16;
+        out[(size_t)y * lv.bpitch + x] = (uint8_t)min(v, 255);
+    }
+}
+
+int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
+    const Plan& P = c->plan;
+    TileTab T;
+    T.nlevels = nlevels;
+    T.cum[0] = 0;
+    for (int L = 0; L < nlevels; L++) {
+        T.tx[L] = (P.lv[L].w + BT_W - 1) / BT_W;
+        int ty = (P.lv[L].h + BT_H - 1) / BT_H;
+        T.cum[L + 1] = T.cum[L] + T.tx[L] * ty;
+    }
+    hipLaunchKernelGGL(k_blur, dim3(T.cum[nlevels], batch), dim3(256), 0, c->stream, P, T, d_gray, c->d_pyr, c->d_blur);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// ------------------------------------------------------------------ FAST ----------------------------
+// circle of radius 3, OpenCV order (dx, dy)
+__constant__ int8_t c_circ[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
+                                     {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+#define FAST_CW 256  // scoring chunk width
+
+__device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has 9 contiguous ones
+    uint32_t m32 = m | (m << 16);
+    uint32_t x = m32 & (m32 >> 1);
+    x &= x >> 2;
+    x &= x >> 4;
+    x &= m32 >> 8;
+    return (x & 0xFFFFu) != 0;
+}
+
+// FAST corner score (cornerScore<16>): for a corner, max over the 16 arcs of 9 of min(d) over the arc, minus 1
+// (d = centre - circle pixel for a dark corner, circle - centre for a bright one).
+__device__ __forceinline__ int arc_score(const int d[16]) {
+    int m2[16], m4[16], best = -1000;
+#pragma unroll
+    for (int i = 0; i < 16; i++) m2[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int m8 = min(m4[i], m4[(i + 4) & 15]);
+        int m9 = min(m8, d[(i + 8) & 15]);
+        best = max(best, m9);
+    }
+    return best - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                              uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int tile_pitch) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int strip = blockIdx.x, frame = blockIdx.y;
+    int L = 0;
+    while (L + 1 < P.nlevels && strip >= P.lv[L + 1].strip_base) L++;
+    const LevelInfo lv = P.lv[L];
+    strip -= lv.strip_base;
+    if (strip >= lv.nstrips) return;
+    const int R = lv.strip_rows;
+    const int y0 = lv.by0 + strip * R;
+    const int rows = min(R, lv.by0 + lv.bh - y0);
+    const int SW = lv.bw + 2;           // scored columns: bx0-1 .. bx0+bw
+    const int xs0 = lv.bx0 - 1;
+    uint8_t* s_score = smem;            // (R+2) rows x SW
+    uint8_t* s_tile = smem + (((R + 2) * SW + 15) & ~15);  // (R+8) rows x tile_pitch
+    __shared__ int s_wsum[4];
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    const int t = P.fast_threshold;
+    const int tid = threadIdx.x;
+
+    for (int cx = 0; cx < SW; cx += FAST_CW) {
+        const int cw = min(FAST_CW, SW - cx);
+        // stage pixels: rows y0-4 .. y0+rows+3, columns xs0+cx-3 .. xs0+cx+cw+2
+        const int tw = cw + 6, th = rows + 8;
+        const int gx0 = xs0 + cx - 3, gy0 = y0 - 4;
+        __syncthreads();
+        for (int i = tid; i < tw * th; i += 256) {
+            int r = i / tw, cc = i - r * tw;
+            s_tile[r * tile_pitch + cc] = img[(size_t)(gy0 + r) * lv.pitch + gx0 + cc];
+        }
+        __syncthreads();
+        for (int i = tid; i < (rows + 2) * FAST_CW; i += 256) {
+            int r = i >> 8, cc = i & (FAST_CW - 1);
+            if (cc >= cw) continue;
+            const uint8_t* p = &s_tile[(r + 3) * tile_pitch + cc + 3];
+            int v = p[0];
+            int d[16];
+            uint32_t md = 0, mb = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                d[k] = v - (int)p[c_circ[k][1] * tile_pitch + c_circ[k][0]];
+                md |= (d[k] > t ? 1u : 0u) << k;
+                mb |= (d[k] < -t ? 1u : 0u) << k;
+            }
+            int sc = 0;
+            bool dark = arc9(md), bright = arc9(mb);
+            if (dark || bright) {
+                if (bright) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) d[k] = -d[k];
+                }
+                sc = arc_score(d);
+            }
+            s_score[r * SW + cx + cc] = (uint8_t)sc;
+        }
+    }
+    __syncthreads();
+
+    // NMS + border filter + raster-ordered compaction.  Items = rows x bw, row-major; each thread owns a
+    // contiguous run so that thread order == raster order.
+    const int nitems = rows * lv.bw;
+    const int ipt = (nitems + 255) / 256;
+    const int i0 = tid * ipt;
+    unsigned long long keep = 0;
+    for (int j = 0; j < ipt; j++) {
+        int i = i0 + j;
+        if (i >= nitems) break;
+        int rr = i / lv.bw, xx = i - rr * lv.bw;
+        const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
+        int sc = s[0];
+        if (sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-SW - 1] && sc > s[-SW] && sc > s[-SW + 1] && sc > s[SW - 1] &&
+            sc > s[SW] && sc > s[SW + 1])
+            keep |= 1ull << j;
+    }
+    int cnt = __popcll(keep);
+    // block exclusive scan of cnt
+    int lane = tid & 63, wv = tid >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int n = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += n;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; k++) base += s_wsum[k];
+    int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    int pos = base + incl - cnt;
+    uint32_t* out = cand + (size_t)frame * P.cand_stride + lv.cand_off + (size_t)strip * lv.strip_cap;
+    while (keep) {
+        int j = __ffsll((long long)keep) - 1;
+        keep &= keep - 1;
+        int i = i0 + j;
+        int rr = i / lv.bw, xx = i - rr * lv.bw;
+        int sc = s_score[(rr + 1) * SW + xx + 1];
+        if (pos < lv.strip_cap) out[pos] = ((uint32_t)sc << 24) | ((uint32_t)(y0 + rr) << 12) | (uint32_t)(lv.bx0 + xx);
+        pos++;
+    }
+    if (tid == 0) strip_cnt[(size_t)frame * P.strips_per_frame + lv.strip_base + strip] = min(total, lv.strip_cap);
+}
+
+static int fast_tile_pitch() { return FAST_CW + 8; }
+
+int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
+    const Plan& P = c->plan;
+    size_t lds = 0;
+    for (int L = 0; L < P.nlevels; L++) {
+        const LevelInfo& v = P.lv[L];
+        size_t a = (((size_t)(v.strip_rows + 2) * (v.bw + 2) + 15) & ~(size_t)15) +
+                   (size_t)(v.strip_rows + 8) * fast_tile_pitch();
+        lds = std::max(lds, a);
+    }
+    if (lds > 150 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
+    if (P.strips_per_frame < 1) return MO_OK;
+    hipLaunchKernelGGL(k_fast, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr,
+                       c->d_cand, c->d_strip_cnt, fast_tile_pitch());
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// ------------------------------------------------------------------ select --------------------------
+#define SEL_ACAP 8192   // u32 records in LDS (FAST pass)
+#define SEL_BCAP 3072   // u64 records in LDS (Harris pass)
+#define SEL_MAXSTRIPS 1024
+
+// Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
+__device__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
+    int a = 0, b = 0, cc = 0;
+    for (int i = -3; i <= 3; i++) {
+        const uint8_t* pm = img + (size_t)(y0 + i - 1) * pitch + x0;
+        const uint8_t* p0 = pm + pitch;
+        const uint8_t* pp = p0 + pitch;
+#pragma unroll
+        for (int j = -3; j <= 3; j++) {
+            int Ix = ((int)p0[j + 1] - (int)p0[j - 1]) * 2 + ((int)pm[j + 1] - (int)pm[j - 1]) +
+                     ((int)pp[j + 1] - (int)pp[j - 1]);
+            int Iy = ((int)pp[j] - (int)pm[j]) * 2 + ((int)pp[j - 1] - (int)pm[j - 1]) + ((int)pp[j + 1] - (int)pm[j + 1]);
+            a += Ix * Ix;
+            b += Iy * Iy;
+            cc += Ix * Iy;
+        }
+    }
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    float fa = (float)a, fb = (float)b, fc = (float)cc;
+    float t1 = fa * fb;
+    float t2 = fc * fc;
+    float s = fa + fb;
+    float t3 = 0.04f * s;
+    float t4 = t3 * s;
+    return ((t1 - t2) - t4) * scale_sq_sq;
+}
+
+// phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota), write-out
+template <class PA, class PB>
+__device__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1, int* s_n,
+                              FinalKp* fin, int* fin_cnt_out, int* flags) {
+    const int lane = threadIdx.x;
+    for (int i = lane; i < N1; i += WAVE) {
+        uint32_t e = A[i];
+        int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
+        float r = harris_response(img, lv.pitch, x, y);
+        B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
+    }
+    __syncthreads();
+    if (lane == 0) s_n[1] = replay::retain_best<uint64_t>(B, N1, lv.quota, P.select_order);
+    __syncthreads();
+    int N2 = s_n[1];
+    if (N2 > lv.fin_cap) {
+        if (lane == 0) atomicOr(&flags[0], 1);
+        N2 = lv.fin_cap;
+    }
+    for (int i = lane; i < N2; i += WAVE) {
+        uint64_t e = B[i];
+        FinalKp k;
+        k.x = (uint16_t)(e & 0xFFF);
+        k.y = (uint16_t)((e >> 12) & 0xFFF);
+        k.response = __uint_as_float((uint32_t)(e >> 32));
+        fin[i] = k;
+    }
+    if (lane == 0) *fin_cnt_out = N2;
+}
+
+__global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                               const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
+                                               uint64_t* __restrict__ scratch, size_t scratch_stride,
+                                               FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags) {
+    __shared__ uint32_t s_A[SEL_ACAP];
+    __shared__ uint64_t s_B[SEL_BCAP];
+    __shared__ int s_pref[SEL_MAXSTRIPS + 1];
+    __shared__ int s_n[2];
+    const int L = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
+    const LevelInfo lv = P.lv[L];
+    int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
+    if (lv.nstrips == 0) {
+        if (lane == 0) *fin_cnt_out = 0;
+        return;
+    }
+    const int* cnts = strip_cnt + (size_t)frame * P.strips_per_frame + lv.strip_base;
+    for (int s = lane; s < lv.nstrips; s += WAVE) s_pref[s + 1] = cnts[s];
+    __syncthreads();
+    if (lane == 0) {
+        s_pref[0] = 0;
+        for (int s = 0; s < lv.nstrips; s++) s_pref[s + 1] += s_pref[s];
+    }
+    __syncthreads();
+    const int N = s_pref[lv.nstrips];
+    uint64_t* scr = scratch + (size_t)frame * scratch_stride + lv.scr_off;
+    uint64_t* gB = scr;                                  // cand_cap u64
+    uint32_t* gA = (uint32_t*)(scr + lv.cand_cap);       // cand_cap u32
+    const bool a_lds = N <= SEL_ACAP;
+    const uint32_t* src = cand + (size_t)frame * P.cand_stride + lv.cand_off;
+    for (int s = 0; s < lv.nstrips; s++) {
+        int b = s_pref[s], n = s_pref[s + 1] - b;
+        const uint32_t* e = src + (size_t)s * lv.strip_cap;
+        if (a_lds) for (int i = lane; i < n; i += WAVE) s_A[b + i] = e[i];
+        else for (int i = lane; i < n; i += WAVE) gA[b + i] = e[i];
+    }
+    __syncthreads();
+    // pass 1: retainBest(2 * quota) on the FAST score, one lane replays the library permutation
+    if (lane == 0) {
+        if (a_lds) s_n[0] = replay::retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order);
+        else s_n[0] = replay::retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order);
+    }
+    __syncthreads();
+    const int N1 = s_n[0];
+    const bool b_lds = N1 <= SEL_BCAP;
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
+    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, s_n, fin, fin_cnt_out, flags);
+    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, s_n, fin, fin_cnt_out, flags);
+    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, s_n, fin, fin_cnt_out, flags);
+    else select_harris(P, lv, img, gA, gB, N1, s_n, fin, fin_cnt_out, flags);
+}
+
+int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
+    const Plan& P = c->plan;
+    for (int L = 0; L < P.nlevels; L++)
+        if (P.lv[L].nstrips > SEL_MAXSTRIPS) return mo_fail(c, MO_ERR_UNSUPPORTED, "too many strips per level");
+    hipLaunchKernelGGL(k_select, dim3(P.nlevels, batch), dim3(64), 0, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// probe for the parity tests: retainBest on a bare float response array (u64 record path)
+__global__ void k_retain_probe(const float* resp, int n, int n_points, int order, uint64_t* rec, int32_t* out, int* nout) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) rec[i] = ((uint64_t)__float_as_uint(resp[i]) << 32) | (uint32_t)i;
+    __syncthreads();
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = replay::retain_best<uint64_t>(rec, n, n_points, order);
+    __syncthreads();
+    for (int i = threadIdx.x; i < s_n; i += blockDim.x) out[i] = (int32_t)(rec[i] & 0xFFFFFFFFu);
+    if (threadIdx.x == 0) *nout = s_n;
+}
+
+int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order, int* d_nout) {
+    size_t need = (size_t)std::max(n, 1) * sizeof(uint64_t);
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, need);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_retain_probe, dim3(1), dim3(64), 0, c->stream, d_resp, n, n_points, order, (uint64_t*)c->d_tmp,
+                       d_order, d_nout);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// ------------------------------------------------------------------ describe ------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 256 rotated binary tests around (cx, cy): lane l does tests 4l..4l+3; even lanes store one byte.
+// BOUNDS: sample positions may leave the level (compute() with caller keypoints on coarse octaves);
+// OpenCV then reads its REFLECT_101 apron, which holds UNBLURRED pixels.
+template <bool BOUNDS>
+__device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, const uint8_t* raw, int rpitch, int lw, int lh,
+                                            int cx, int cy, float angle_deg, uint8_t* desc, int lane) {
+    float angle = angle_deg;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    unsigned nib = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int8_t* pt = &c_pattern[(lane * 4 + k) * 4];
+        float fx0 = (float)pt[0], fy0 = (float)pt[1], fx1 = (float)pt[2], fy1 = (float)pt[3];
+        int ix0 = __float2int_rn(fx0 * a - fy0 * b), iy0 = __float2int_rn(fx0 * b + fy0 * a);
+        int ix1 = __float2int_rn(fx1 * a - fy1 * b), iy1 = __float2int_rn(fx1 * b + fy1 * a);
+        int x0 = cx + ix0, y0 = cy + iy0, x1 = cx + ix1, y1 = cy + iy1;
+        int t0, t1;
+        if (BOUNDS) {
+            t0 = (x0 >= 0 && x0 < lw && y0 >= 0 && y0 < lh) ? blur[(size_t)y0 * bpitch + x0]
+                                                           : raw[(size_t)reflect101(y0, lh) * rpitch + reflect101(x0, lw)];
+            t1 = (x1 >= 0 && x1 < lw && y1 >= 0 && y1 < lh) ? blur[(size_t)y1 * bpitch + x1]
+                                                           : raw[(size_t)reflect101(y1, lh) * rpitch + reflect101(x1, lw)];
+        } else {
+            t0 = blur[(size_t)y0 * bpitch + x0];
+            t1 = blur[(size_t)y1 * bpitch + x1];
+        }
+        nib |= (t0 < t1 ? 1u : 0u) << k;
+    }
+    unsigned hi = __shfl_down(nib, 1, 64);
+    if ((lane & 1) == 0) desc[lane >> 1] = (uint8_t)(nib | (hi << 4));
+}
+
+__global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                                  const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
+                                                  const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
+                                                  uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
+                                                  int* flags) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
+    int total = 0, L = -1, idx = 0;
+    for (int l = 0; l < P.nlevels; l++) {
+        int n = fc[l];
+        if (L < 0 && k < total + n) { L = l; idx = k - total; }
+        total += n;
+    }
+    if (k == 0 && lane == 0) {
+        counts[frame] = total;
+        if (total > cap) atomicOr(&flags[0], 2);
+    }
+    if (L < 0 || k >= cap) return;
+    const LevelInfo lv = P.lv[L];
+    FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    const int x = fk.x, y = fk.y;
+    // intensity centroid over the radius-15 disc: one row per lane
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+        int v = lane - 15;
+        int d = P.umax[v < 0 ? -v : v];
+        const uint8_t* row = img + (size_t)(y + v) * lv.pitch + x;
+        int rs = 0;
+        for (int u = -d; u <= d; u++) {
+            int p = row[u];
+            m10 += u * p;
+            rs += p;
+        }
+        m01 = v * rs;
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    float angle = fast_atan2_deg((float)m01, (float)m10);
+    float px = (float)x * lv.scale, py = (float)y * lv.scale;
+    mo_keypoint* o = kps + (size_t)frame * cap + k;
+    if (lane == 0) {
+        o->x = px; o->y = py;
+        o->size = 31 * lv.scale;
+        o->angle = angle;
+        o->response = fk.response;
+        o->octave = L;
+        o->class_id = -1;
+    }
+    if (desc) {
+        float inv = 1.f / lv.scale;
+        int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
+        const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
+        rbrief_wave<false>(bl, lv.bpitch, img, lv.pitch, lv.w, lv.h, cx, cy, angle, desc + ((size_t)frame * cap + k) * 32, lane);
+    }
+}
+
+int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
+                        int* d_counts) {
+    const Plan& P = c->plan;
+    hipLaunchKernelGGL(k_describe, dim3((cap + 3) / 4, batch), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur,
+                       c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->d_flags);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// compute() with caller keypoints (frame 0 of the context buffers): angle as supplied, level = kp.octave
+__global__ __launch_bounds__(256) void k_describe_given(Plan P, const uint8_t* __restrict__ gray,
+                                                        const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
+                                                        const mo_keypoint* __restrict__ kps, int n,
+                                                        uint8_t* __restrict__ desc) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    mo_keypoint kp = kps[k];
+    const int L = kp.octave;
+    const LevelInfo lv = P.lv[L];
+    float inv = 1.f / lv.scale;
+    int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
+    const uint8_t* img = level_ptr(P, L, gray, pyr, 0);
+    const uint8_t* bl = blur + lv.boff;
+    rbrief_wave<true>(bl, lv.bpitch, img, lv.pitch, lv.w, lv.h, cx, cy, kp.angle, desc + (size_t)k * 32, lane);
+}
+
+int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc) {
+    if (n <= 0) return MO_OK;
+    const Plan& P = c->plan;
+    hipLaunchKernelGGL(k_describe_given, dim3((n + 3) / 4), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, d_kps,
+                       n, d_desc);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}

@@ -1,0 +1,283 @@
+// select_replay.h -- device-side replay of KeyPointsFilter::retainBest (OpenCV features2d keypoint.cpp),
+// i.e. std::nth_element + std::partition, reproducing the exact permutation of the C++ standard library
+// the cv2 wheel was linked against.  The SET retainBest keeps is order-independent; the ORDER it leaves
+// the survivors in (= the order of cv2's keypoints, hence every queryIdx/trainIdx downstream) is the
+// standard library's introselect permutation, so it is restated here step by step:
+//   * MO_ORDER_LIBSTDCXX: libstdc++ __introselect (median-of-3 to first, unguarded Hoare partition,
+//     heap-select fallback at depth 2*lg(n), insertion sort of the last <= 3)
+//   * MO_ORDER_MSVC: MSVC STL nth_element (ninther / median-of-3 guess, three-way partition around the
+//     pivot's equal range, insertion sort of the last <= 32) -- the order of the reference's gt.yaml.
+// Reference call sites: src/orbslam2/extractor.py:65 (orb.detectAndCompute -> computeKeyPoints ->
+// retainBest twice per level).
+//
+// These are sequential algorithms; one lane replays them on a record array that lives in LDS (or in an
+// HBM scratch slot when the level has more candidates than the LDS window).  Records:
+//   uint32_t: FAST pass   -- score in bits 31..24, packed (y<<12|x) position in bits 23..0
+//   uint64_t: Harris pass -- float response bits in 63..32, packed position in 31..0
+#pragma once
+#include <stdint.h>
+
+namespace replay {
+
+template <class T> struct Rec;
+template <> struct Rec<uint32_t> {
+    static __device__ __forceinline__ bool gt(uint32_t a, uint32_t b) { return (a >> 24) > (b >> 24); }
+    static __device__ __forceinline__ bool ge(uint32_t a, uint32_t b) { return (a >> 24) >= (b >> 24); }
+};
+template <> struct Rec<uint64_t> {
+    static __device__ __forceinline__ float f(uint64_t a) { return __uint_as_float((uint32_t)(a >> 32)); }
+    static __device__ __forceinline__ bool gt(uint64_t a, uint64_t b) { return f(a) > f(b); }
+    static __device__ __forceinline__ bool ge(uint64_t a, uint64_t b) { return f(a) >= f(b); }
+};
+
+template <class P> __device__ __forceinline__ void swp(P a, int i, int j) {
+    auto t = a[i];
+    a[i] = a[j];
+    a[j] = t;
+}
+
+// ---------------------------------------------------------------- libstdc++ ------------------------
+template <class T, class P> __device__ void ls_move_median_to_first(P a, int result, int ia, int ib, int ic) {
+    typedef Rec<T> R;
+    if (R::gt(a[ia], a[ib])) {
+        if (R::gt(a[ib], a[ic])) swp(a, result, ib);
+        else if (R::gt(a[ia], a[ic])) swp(a, result, ic);
+        else swp(a, result, ia);
+    } else if (R::gt(a[ia], a[ic])) swp(a, result, ia);
+    else if (R::gt(a[ib], a[ic])) swp(a, result, ic);
+    else swp(a, result, ib);
+}
+
+template <class T, class P> __device__ int ls_unguarded_partition(P a, int first, int last, int pivot) {
+    typedef Rec<T> R;
+    const T pv = a[pivot];
+    while (true) {
+        while (R::gt(a[first], pv)) ++first;
+        --last;
+        while (R::gt(pv, a[last])) --last;
+        if (!(first < last)) return first;
+        swp(a, first, last);
+        ++first;
+    }
+}
+
+template <class T, class P> __device__ void ls_push_heap(P a, int first, int hole, int top, T value) {
+    typedef Rec<T> R;
+    int parent = (hole - 1) / 2;
+    while (hole > top && R::gt(a[first + parent], value)) {
+        a[first + hole] = a[first + parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[first + hole] = value;
+}
+
+template <class T, class P> __device__ void ls_adjust_heap(P a, int first, int hole, int len, T value) {
+    typedef Rec<T> R;
+    const int top = hole;
+    int second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (R::gt(a[first + second], a[first + (second - 1)])) second--;
+        a[first + hole] = a[first + second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        a[first + hole] = a[first + (second - 1)];
+        hole = second - 1;
+    }
+    ls_push_heap<T>(a, first, hole, top, value);
+}
+
+template <class T, class P> __device__ void ls_heap_select(P a, int first, int middle, int last) {
+    typedef Rec<T> R;
+    // __make_heap(first, middle)
+    int len = middle - first;
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            T v = a[first + parent];
+            ls_adjust_heap<T>(a, first, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    for (int i = middle; i < last; ++i) {
+        if (R::gt(a[i], a[first])) {
+            // __pop_heap(first, middle, i)
+            T v = a[i];
+            a[i] = a[first];
+            ls_adjust_heap<T>(a, first, 0, middle - first, v);
+        }
+    }
+}
+
+template <class T, class P> __device__ void ls_insertion_sort(P a, int first, int last) {
+    typedef Rec<T> R;
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        T val = a[i];
+        if (R::gt(val, a[first])) {
+            for (int k = i; k > first; --k) a[k] = a[k - 1];
+            a[first] = val;
+        } else {
+            int l = i, next = i - 1;
+            while (R::gt(val, a[next])) {
+                a[l] = a[next];
+                l = next;
+                --next;
+            }
+            a[l] = val;
+        }
+    }
+}
+
+template <class T, class P> __device__ void ls_nth_element(P a, int first, int nth, int last) {
+    if (first == last || nth == last) return;
+    int depth = (31 - __clz(last - first)) * 2;
+    while (last - first > 3) {
+        if (depth == 0) {
+            ls_heap_select<T>(a, first, nth + 1, last);
+            swp(a, first, nth);
+            return;
+        }
+        --depth;
+        int mid = first + (last - first) / 2;
+        ls_move_median_to_first<T>(a, first, first + 1, mid, last - 1);
+        int cut = ls_unguarded_partition<T>(a, first + 1, last, first);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    ls_insertion_sort<T>(a, first, last);
+}
+
+// ---------------------------------------------------------------- MSVC STL -------------------------
+template <class T, class P> __device__ void ms_med3(P a, int first, int mid, int last) {
+    typedef Rec<T> R;
+    if (R::gt(a[mid], a[first])) swp(a, mid, first);
+    if (R::gt(a[last], a[mid])) {
+        swp(a, last, mid);
+        if (R::gt(a[mid], a[first])) swp(a, mid, first);
+    }
+}
+
+template <class T, class P> __device__ void ms_guess_median(P a, int first, int mid, int last) {  // last inclusive
+    const int count = last - first;
+    if (40 < count) {
+        const int step = (count + 1) >> 3;
+        const int two_step = step << 1;
+        ms_med3<T>(a, first, first + step, first + two_step);
+        ms_med3<T>(a, mid - step, mid, mid + step);
+        ms_med3<T>(a, last - two_step, last - step, last);
+        ms_med3<T>(a, first + step, mid, last - step);
+    } else {
+        ms_med3<T>(a, first, mid, last);
+    }
+}
+
+template <class T, class P> __device__ void ms_partition(P a, int first, int last, int& out_first, int& out_last) {
+    typedef Rec<T> R;
+    int mid = first + ((last - first) >> 1);
+    ms_guess_median<T>(a, first, mid, last - 1);
+    int pfirst = mid;
+    int plast = pfirst + 1;
+    while (first < pfirst && !R::gt(a[pfirst - 1], a[pfirst]) && !R::gt(a[pfirst], a[pfirst - 1])) --pfirst;
+    while (plast < last && !R::gt(a[plast], a[pfirst]) && !R::gt(a[pfirst], a[plast])) ++plast;
+    int gfirst = plast;
+    int glast = pfirst;
+    for (;;) {
+        for (; gfirst < last; ++gfirst) {
+            if (R::gt(a[pfirst], a[gfirst])) continue;
+            else if (R::gt(a[gfirst], a[pfirst])) break;
+            else if (plast != gfirst) { swp(a, plast, gfirst); ++plast; }
+            else ++plast;
+        }
+        for (; first < glast; --glast) {
+            if (R::gt(a[glast - 1], a[pfirst])) continue;
+            else if (R::gt(a[pfirst], a[glast - 1])) break;
+            else if (--pfirst != glast - 1) swp(a, pfirst, glast - 1);
+        }
+        if (glast == first && gfirst == last) { out_first = pfirst; out_last = plast; return; }
+        if (glast == first) {
+            if (plast != gfirst) swp(a, pfirst, plast);
+            ++plast;
+            swp(a, pfirst, gfirst);
+            ++pfirst;
+            ++gfirst;
+        } else if (gfirst == last) {
+            if (--glast != --pfirst) swp(a, glast, pfirst);
+            swp(a, pfirst, --plast);
+        } else {
+            swp(a, gfirst, --glast);
+            ++gfirst;
+        }
+    }
+}
+
+template <class T, class P> __device__ void ms_insertion_sort(P a, int first, int last) {
+    typedef Rec<T> R;
+    if (first == last) return;
+    for (int mid = first + 1; mid != last; ++mid) {
+        int hole = mid;
+        T val = a[mid];
+        if (R::gt(val, a[first])) {
+            for (int k = mid; k > first; --k) a[k] = a[k - 1];
+            a[first] = val;
+        } else {
+            int prev = hole - 1;
+            while (R::gt(val, a[prev])) {
+                a[hole] = a[prev];
+                hole = prev;
+                --prev;
+            }
+            a[hole] = val;
+        }
+    }
+}
+
+template <class T, class P> __device__ void ms_nth_element(P a, int first, int nth, int last) {
+    if (nth == last) return;
+    while (32 < last - first) {
+        int mf, ml;
+        ms_partition<T>(a, first, last, mf, ml);
+        if (ml <= nth) first = ml;
+        else if (mf <= nth) return;
+        else last = mf;
+    }
+    ms_insertion_sort<T>(a, first, last);
+}
+
+// std::partition (bidirectional form, same permutation in libstdc++ and the MSVC STL):
+// elements with response >= thr first.  Returns the number of elements satisfying the predicate.
+template <class T, class P> __device__ int partition_ge(P a, int first, int last, T thr) {
+    typedef Rec<T> R;
+    const int begin = first;
+    while (true) {
+        while (true) {
+            if (first == last) return first - begin;
+            else if (R::ge(a[first], thr)) ++first;
+            else break;
+        }
+        --last;
+        while (true) {
+            if (first == last) return first - begin;
+            else if (!R::ge(a[last], thr)) --last;
+            else break;
+        }
+        swp(a, first, last);
+        ++first;
+    }
+}
+
+// KeyPointsFilter::retainBest on records a[0..n): returns the surviving count, survivors in a[0..ret)
+template <class T, class P> __device__ int retain_best(P a, int n, int n_points, int order) {
+    if (n_points < 0 || n <= n_points) return n;
+    if (n_points == 0) return 0;
+    if (order == MO_ORDER_MSVC) ms_nth_element<T>(a, 0, n_points - 1, n);
+    else ls_nth_element<T>(a, 0, n_points - 1, n);
+    T amb = a[n_points - 1];
+    return n_points + partition_ge<T>(a, n_points, n, amb);
+}
+
+}  // namespace replay

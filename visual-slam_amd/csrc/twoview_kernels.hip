@@ -1,0 +1,581 @@
+// twoview_kernels.hip -- two-view initialisation on gfx950 (fp64 vector ALU; no MFMA: tiny per-thread solves).
+// Replaces, for the reference's MapInitializer.initialize (src/orbslam2/initializer.py:75-120):
+//   utils.py:120-126  cv2.findEssentialMat(p1, p2, K, RANSAC, prob, threshold)  -> k_tv_hyp + k_tv_finish
+//   utils.py:129-134  cv2.recoverPose(E, p1, p2, K, mask)                        -> k_tv_finish (cheirality vote)
+//   utils.py:56-70    cv2.triangulatePoints + divide by w                        -> k_tv_finish (DLT)
+// north_star prescribes an 8-point essential-matrix RANSAC with thousands of hypotheses scored in parallel
+// (cv2 itself runs a sequential 5-point RANSAC), so parity here is on the recovered R, t, X (1e-4 rel), not
+// on hypothesis-level equality with cv2.
+//
+//   k_tv_prep    per pair: gather the ratio-test survivors (query order) -> normalised f64 correspondences
+//   k_tv_hyp     one thread per hypothesis: counter-based 8-sample, 8x9 null vector by full-pivot Gauss-Jordan,
+//                projection on the essential manifold (3x3 SVD via Jacobi), Sampson inlier count over all
+//                correspondences staged in LDS; block max -> one atomicMax per block
+//   k_tv_finish  one block per pair: consensus set of the best hypothesis -> least-squares 8-point refit
+//                (9x9 normal matrix, Jacobi) -> final inliers -> decompose E -> cheirality vote over the 4
+//                (R, t) candidates with per-point DLT -> final DLT triangulation in pixel space
+#include <cmath>
+
+#include "common.h"
+
+#define TV_BLOCK 256
+
+struct TvWork {
+    double* xn;        // [pairs][cap][4] normalised x1,y1,x2,y2
+    float* px;         // [pairs][cap][4] pixel u1,v1,u2,v2
+    int* qidx;         // [pairs][cap] query keypoint index of correspondence i
+    int* m;            // [pairs]
+    double* hypE;      // [pairs][n_hyp][9]
+    unsigned long long* best;  // [pairs] (count << 32) | (0xFFFFFFFF - hyp)
+};
+
+size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
+    size_t p = (size_t)n_pairs;
+    return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 +
+           p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + 1024;
+}
+
+static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
+    TvWork w;
+    uint8_t* b = (uint8_t*)base;
+    size_t p = (size_t)n_pairs;
+    w.xn = (double*)b; b += p * cap * 4 * sizeof(double);
+    w.hypE = (double*)b; b += p * (size_t)n_hyp * 9 * sizeof(double);
+    w.best = (unsigned long long*)b; b += p * sizeof(unsigned long long);
+    w.px = (float*)b; b += p * cap * 4 * sizeof(float);
+    w.qidx = (int*)b; b += p * cap * sizeof(int);
+    w.m = (int*)b;
+    return w;
+}
+
+// ---------------------------------------------------------------- small dense helpers -------------
+// cyclic Jacobi eigen-decomposition of a symmetric NxN matrix (row-major a, eigenvectors in columns of v)
+template <int N> __device__ void jacobi_eig(double* a, double* v) {
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) v[i * N + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) {
+                if (i != j) off += a[i * N + j] * a[i * N + j];
+                else diag += a[i * N + j] * a[i * N + j];
+            }
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                double apq = a[p * N + q];
+                if (apq == 0.0) continue;
+                double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < N; k++) {
+                    double akp = a[k * N + p], akq = a[k * N + q];
+                    a[k * N + p] = c * akp - s * akq;
+                    a[k * N + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < N; k++) {
+                    double apk = a[p * N + k], aqk = a[q * N + k];
+                    a[p * N + k] = c * apk - s * aqk;
+                    a[q * N + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < N; k++) {
+                    double vkp = v[k * N + p], vkq = v[k * N + q];
+                    v[k * N + p] = c * vkp - s * vkq;
+                    v[k * N + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+__device__ inline void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// SVD of a (near) rank-2 3x3 matrix E (row-major): right vectors from eig(E^T E), u_i = E v_i / sigma_i for the
+// two largest, third vectors by cross products so det(U) = det(V) = +1.  Returns false when degenerate.
+__device__ bool svd3_rank2(const double* E, double* U, double* V, double* sig) {
+    double a[9], v[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) a[i * 3 + j] = E[0 * 3 + i] * E[0 * 3 + j] + E[1 * 3 + i] * E[1 * 3 + j] + E[2 * 3 + i] * E[2 * 3 + j];
+    jacobi_eig<3>(a, v);
+    int o0 = 0, o1 = 1, o2 = 2;
+    double l[3] = {a[0], a[4], a[8]};
+    if (l[o0] < l[o1]) { int t = o0; o0 = o1; o1 = t; }
+    if (l[o1] < l[o2]) { int t = o1; o1 = o2; o2 = t; }
+    if (l[o0] < l[o1]) { int t = o0; o0 = o1; o1 = t; }
+    double v1[3] = {v[0 * 3 + o0], v[1 * 3 + o0], v[2 * 3 + o0]};
+    double v2[3] = {v[0 * 3 + o1], v[1 * 3 + o1], v[2 * 3 + o1]};
+    double s1 = sqrt(fmax(l[o0], 0.0)), s2 = sqrt(fmax(l[o1], 0.0));
+    if (!(s2 > 1e-12 * s1) || !(s1 > 0)) return false;
+    double u1[3], u2[3], u3[3], v3[3];
+    for (int i = 0; i < 3; i++) {
+        u1[i] = (E[i * 3] * v1[0] + E[i * 3 + 1] * v1[1] + E[i * 3 + 2] * v1[2]) / s1;
+        u2[i] = (E[i * 3] * v2[0] + E[i * 3 + 1] * v2[1] + E[i * 3 + 2] * v2[2]) / s2;
+    }
+    // re-orthogonalise u2 against u1 (they are orthogonal up to rounding)
+    double d = u1[0] * u2[0] + u1[1] * u2[1] + u1[2] * u2[2];
+    for (int i = 0; i < 3; i++) u2[i] -= d * u1[i];
+    double n2 = sqrt(u2[0] * u2[0] + u2[1] * u2[1] + u2[2] * u2[2]);
+    double n1 = sqrt(u1[0] * u1[0] + u1[1] * u1[1] + u1[2] * u1[2]);
+    if (!(n1 > 0) || !(n2 > 0)) return false;
+    for (int i = 0; i < 3; i++) { u1[i] /= n1; u2[i] /= n2; }
+    cross3(u1, u2, u3);
+    cross3(v1, v2, v3);
+    for (int i = 0; i < 3; i++) {
+        U[i * 3] = u1[i]; U[i * 3 + 1] = u2[i]; U[i * 3 + 2] = u3[i];
+        V[i * 3] = v1[i]; V[i * 3 + 1] = v2[i]; V[i * 3 + 2] = v3[i];
+    }
+    sig[0] = s1; sig[1] = s2; sig[2] = sqrt(fmax(l[o2], 0.0));
+    return true;
+}
+
+// nearest essential matrix (singular values 1, 1, 0)
+__device__ bool project_essential(double* E) {
+    double U[9], V[9], s[3];
+    if (!svd3_rank2(E, U, V, s)) return false;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) E[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1];
+    return true;
+}
+
+__device__ inline double sampson(const double* E, double x1, double y1, double x2, double y2) {
+    double ex0 = E[0] * x1 + E[1] * y1 + E[2];
+    double ex1 = E[3] * x1 + E[4] * y1 + E[5];
+    double ex2 = E[6] * x1 + E[7] * y1 + E[8];
+    double et0 = E[0] * x2 + E[3] * y2 + E[6];
+    double et1 = E[1] * x2 + E[4] * y2 + E[7];
+    double num = x2 * ex0 + y2 * ex1 + ex2;
+    double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
+    return num * num / den;
+}
+
+__device__ inline uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// 8 distinct sample indices of hypothesis h (shared definition with oracle/geom_oracle.py)
+__device__ inline void sample8(uint64_t seed, int h, int m, int* idx) {
+    uint64_t s = seed + (uint64_t)(h + 1) * 0xD1B54A32D192ED03ull;
+    for (int k = 0; k < 8; k++) {
+        while (true) {
+            int c = (int)(splitmix64(s) % (uint64_t)m);
+            bool dup = false;
+            for (int j = 0; j < k; j++) dup |= idx[j] == c;
+            if (!dup) { idx[k] = c; break; }
+        }
+    }
+}
+
+// null vector of the 8x9 epipolar constraint matrix by Gauss-Jordan with full pivoting
+__device__ bool eight_point(const double* pts /* [8][4] */, double* E) {
+    double A[8][9];
+    for (int k = 0; k < 8; k++) {
+        double x1 = pts[k * 4], y1 = pts[k * 4 + 1], x2 = pts[k * 4 + 2], y2 = pts[k * 4 + 3];
+        A[k][0] = x2 * x1; A[k][1] = x2 * y1; A[k][2] = x2;
+        A[k][3] = y2 * x1; A[k][4] = y2 * y1; A[k][5] = y2;
+        A[k][6] = x1;      A[k][7] = y1;      A[k][8] = 1.0;
+    }
+    int colperm[9];
+    for (int j = 0; j < 9; j++) colperm[j] = j;
+    double amax0 = 0;
+    for (int r = 0; r < 8; r++) {
+        int pr = r, pc = r;
+        double best = -1;
+        for (int i = r; i < 8; i++)
+            for (int j = r; j < 9; j++) {
+                double v = fabs(A[i][j]);
+                if (v > best) { best = v; pr = i; pc = j; }
+            }
+        if (r == 0) amax0 = best;
+        if (!(best > 1e-13 * amax0)) return false;
+        if (pr != r) for (int j = 0; j < 9; j++) { double t = A[r][j]; A[r][j] = A[pr][j]; A[pr][j] = t; }
+        if (pc != r) {
+            for (int i = 0; i < 8; i++) { double t = A[i][r]; A[i][r] = A[i][pc]; A[i][pc] = t; }
+            int t = colperm[r]; colperm[r] = colperm[pc]; colperm[pc] = t;
+        }
+        double inv = 1.0 / A[r][r];
+        for (int j = r; j < 9; j++) A[r][j] *= inv;
+        for (int i = 0; i < 8; i++) {
+            if (i == r) continue;
+            double f = A[i][r];
+            if (f == 0.0) continue;
+            for (int j = r; j < 9; j++) A[i][j] -= f * A[r][j];
+        }
+    }
+    double e[9];
+    e[colperm[8]] = 1.0;
+    for (int r = 0; r < 8; r++) e[colperm[r]] = -A[r][8];
+    double n = 0;
+    for (int j = 0; j < 9; j++) n += e[j] * e[j];
+    n = 1.0 / sqrt(n);
+    for (int j = 0; j < 9; j++) E[j] = e[j] * n;
+    return true;
+}
+
+// ---------------------------------------------------------------- prep ----------------------------
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_w[TV_BLOCK / 64];
+    __shared__ int s_base;
+    const double fx = a.K[0], fy = a.K[4], cx = a.K[2], cy = a.K[5];
+    double* xn = w.xn + (size_t)pair * a.cap * 4;
+    float* px = w.px + (size_t)pair * a.cap * 4;
+    int* qidx = w.qidx + (size_t)pair * a.cap;
+    if (tid == 0) { s_base = 0; w.best[pair] = 0ull; }
+    __syncthreads();
+    if (a.d_p1) {  // explicit correspondences
+        int m = a.m_fixed;
+        for (int i = tid; i < m; i += TV_BLOCK) {
+            float u1 = a.d_p1[(size_t)pair * m * 2 + 2 * i], v1 = a.d_p1[(size_t)pair * m * 2 + 2 * i + 1];
+            float u2 = a.d_p2[(size_t)pair * m * 2 + 2 * i], v2 = a.d_p2[(size_t)pair * m * 2 + 2 * i + 1];
+            px[4 * i] = u1; px[4 * i + 1] = v1; px[4 * i + 2] = u2; px[4 * i + 3] = v2;
+            xn[4 * i] = ((double)u1 - cx) / fx; xn[4 * i + 1] = ((double)v1 - cy) / fy;
+            xn[4 * i + 2] = ((double)u2 - cx) / fx; xn[4 * i + 3] = ((double)v2 - cy) / fy;
+            qidx[i] = i;
+        }
+        if (tid == 0) w.m[pair] = m;
+        return;
+    }
+    // from matcher output: pair p = frame p (query) vs frame p+1 (train); survivors in query order
+    const int nq = min(a.d_counts[pair], a.cap);
+    const mo_keypoint* k1 = a.d_kps + (size_t)pair * a.cap;
+    const mo_keypoint* k2 = a.d_kps + (size_t)(pair + 1) * a.cap;
+    const int32_t* midx = a.d_match_idx + (size_t)pair * a.cap * 2;
+    const uint8_t* pass = a.d_match_pass + (size_t)pair * a.cap;
+    for (int base = 0; base < nq; base += TV_BLOCK) {
+        int i = base + tid;
+        bool ok = i < nq && pass[i];
+        unsigned long long bal = __ballot(ok);
+        int lane = tid & 63, wv = tid >> 6;
+        int wpre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_w[wv] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int k = 0; k < wv; k++) off += s_w[k];
+        if (ok) {
+            int o = off + wpre;
+            int j = midx[2 * i];
+            float u1 = k1[i].x, v1 = k1[i].y, u2 = k2[j].x, v2 = k2[j].y;
+            px[4 * o] = u1; px[4 * o + 1] = v1; px[4 * o + 2] = u2; px[4 * o + 3] = v2;
+            xn[4 * o] = ((double)u1 - cx) / fx; xn[4 * o + 1] = ((double)v1 - cy) / fy;
+            xn[4 * o + 2] = ((double)u2 - cx) / fx; xn[4 * o + 3] = ((double)v2 - cy) / fy;
+            qidx[o] = i;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    if (tid == 0) w.m[pair] = s_base;
+}
+
+// ---------------------------------------------------------------- hypotheses ----------------------
+#define TV_CHUNK 1024  // correspondences staged in LDS per pass (32 KB)
+
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
+    __shared__ double s_pts[TV_CHUNK * 4];
+    __shared__ unsigned long long s_best[TV_BLOCK / 64];
+    const int pair = blockIdx.y, tid = threadIdx.x;
+    const int h = blockIdx.x * TV_BLOCK + tid;
+    const int m = w.m[pair];
+    if (m < 8) return;
+    const double* xn = w.xn + (size_t)pair * a.cap * 4;
+    const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+    const double thr2 = thr * thr;
+    double E[9];
+    bool valid = h < a.n_hyp;
+    if (valid) {
+        int idx[8];
+        sample8(a.seed + (uint64_t)pair * 0x632BE59BD9B4E019ull, h, m, idx);
+        double pts[32];
+        for (int k = 0; k < 8; k++)
+            for (int j = 0; j < 4; j++) pts[k * 4 + j] = xn[(size_t)idx[k] * 4 + j];
+        valid = eight_point(pts, E) && project_essential(E);
+    }
+    if (!valid) for (int j = 0; j < 9; j++) E[j] = 0.0;
+    if (h < a.n_hyp) {
+        double* o = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
+        for (int j = 0; j < 9; j++) o[j] = E[j];
+    }
+    int count = 0;
+    for (int base = 0; base < m; base += TV_CHUNK) {
+        int n = min(TV_CHUNK, m - base);
+        __syncthreads();
+        for (int i = tid; i < n * 4; i += TV_BLOCK) s_pts[i] = xn[(size_t)base * 4 + i];
+        __syncthreads();
+        if (valid) {
+            for (int i = 0; i < n; i++) {
+                double err = sampson(E, s_pts[4 * i], s_pts[4 * i + 1], s_pts[4 * i + 2], s_pts[4 * i + 3]);
+                count += err <= thr2 ? 1 : 0;
+            }
+        }
+    }
+    unsigned long long key = valid ? (((unsigned long long)count << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h)) : 0ull;
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(key, o, 64);
+        key = other > key ? other : key;
+    }
+    if ((tid & 63) == 0) s_best[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < TV_BLOCK / 64; k++) key = s_best[k] > key ? s_best[k] : key;
+        if (key) atomicMax(&w.best[pair], key);
+    }
+}
+
+// ---------------------------------------------------------------- finish --------------------------
+// DLT null vector of the 4x4 system [x*P3-P1; y*P3-P2] for two views (smallest eigenvector of A^T A)
+__device__ void dlt_point(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double* X) {
+    double A[16];
+    for (int k = 0; k < 4; k++) {
+        A[0 * 4 + k] = x1 * P1[8 + k] - P1[k];
+        A[1 * 4 + k] = y1 * P1[8 + k] - P1[4 + k];
+        A[2 * 4 + k] = x2 * P2[8 + k] - P2[k];
+        A[3 * 4 + k] = y2 * P2[8 + k] - P2[4 + k];
+    }
+    double S[16], V[16];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) S[i * 4 + j] = A[i] * A[j] + A[4 + i] * A[4 + j] + A[8 + i] * A[8 + j] + A[12 + i] * A[12 + j];
+    jacobi_eig<4>(S, V);
+    int mn = 0;
+    for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[mn * 4 + mn]) mn = i;
+    for (int i = 0; i < 4; i++) X[i] = V[i * 4 + mn];
+}
+
+__device__ inline double block_sum(double v, double* s_red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+    for (int k = 0; k < TV_BLOCK / 64; k++) r += s_red[k];
+    return r;
+}
+
+__device__ inline int block_sum_i(int v, int* s_red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = 0;
+    for (int k = 0; k < TV_BLOCK / 64; k++) r += s_red[k];
+    return r;
+}
+
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w) {
+    __shared__ double s_red[TV_BLOCK / 64];
+    __shared__ int s_redi[TV_BLOCK / 64];
+    __shared__ double s_E[9];
+    __shared__ double s_P[4][12];   // candidate [R|t] in normalised coordinates
+    __shared__ double s_Ppix[2][12];
+    __shared__ int s_ok, s_win;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int m = w.m[pair];
+    double* pose = a.d_pose ? a.d_pose + (size_t)pair * 12 : nullptr;
+    float* Xout = a.d_points + (size_t)pair * a.cap * 3;
+    uint8_t* inl_out = a.d_inlier ? a.d_inlier + (size_t)pair * a.cap : nullptr;
+    uint8_t* ran_out = a.d_ransac ? a.d_ransac + (size_t)pair * a.cap : nullptr;
+    const int out_n = a.d_p1 ? a.m_fixed : a.cap;
+    const float qnan = __uint_as_float(0x7FC00000u);
+    for (int i = tid; i < out_n; i += TV_BLOCK) {
+        Xout[3 * i] = qnan; Xout[3 * i + 1] = qnan; Xout[3 * i + 2] = qnan;
+        if (inl_out) inl_out[i] = 0;
+        if (ran_out) ran_out[i] = 0;
+    }
+    const unsigned long long best = w.best[pair];
+    if (m < 8 || best == 0ull) {
+        if (tid == 0) {
+            a.d_n_points[pair] = 0;
+            if (pose) for (int j = 0; j < 12; j++) pose[j] = __longlong_as_double(0x7FF8000000000000ll);
+            if (a.d_E) for (int j = 0; j < 9; j++) a.d_E[(size_t)pair * 9 + j] = __longlong_as_double(0x7FF8000000000000ll);
+        }
+        return;
+    }
+    const int hbest = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+    const double* xn = w.xn + (size_t)pair * a.cap * 4;
+    const float* px = w.px + (size_t)pair * a.cap * 4;
+    const int* qidx = w.qidx + (size_t)pair * a.cap;
+    const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+    const double thr2 = thr * thr;
+    if (tid < 9) s_E[tid] = w.hypE[((size_t)pair * a.n_hyp + hbest) * 9 + tid];
+    __syncthreads();
+
+    // ---- least-squares refit on the consensus set: accumulate the 9x9 normal matrix (45 unique sums)
+    double acc[45];
+    for (int j = 0; j < 45; j++) acc[j] = 0;
+    {
+        double E[9];
+        for (int j = 0; j < 9; j++) E[j] = s_E[j];
+        for (int i = tid; i < m; i += TV_BLOCK) {
+            double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
+            if (sampson(E, x1, y1, x2, y2) <= thr2) {
+                double r[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+                int k = 0;
+#pragma unroll
+                for (int p = 0; p < 9; p++)
+#pragma unroll
+                    for (int q = p; q < 9; q++) acc[k++] += r[p] * r[q];
+            }
+        }
+    }
+    __shared__ double s_N[45];
+    for (int j = 0; j < 45; j++) {
+        double v = block_sum(acc[j], s_red);
+        if (tid == 0) s_N[j] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double A[81], V[81];
+        int k = 0;
+        for (int p = 0; p < 9; p++)
+            for (int q = p; q < 9; q++) { A[p * 9 + q] = s_N[k]; A[q * 9 + p] = s_N[k]; k++; }
+        jacobi_eig<9>(A, V);
+        int mn = 0;
+        for (int i = 1; i < 9; i++) if (A[i * 9 + i] < A[mn * 9 + mn]) mn = i;
+        double E[9];
+        for (int i = 0; i < 9; i++) E[i] = V[i * 9 + mn];
+        bool ok = project_essential(E);
+        if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the best hypothesis
+        // decompose: R1 = U W V^T, R2 = U W^T V^T, t = u3
+        double U[9], Vm[9], sg[3], Ef[9];
+        for (int i = 0; i < 9; i++) Ef[i] = s_E[i];
+        s_ok = svd3_rank2(Ef, U, Vm, sg) ? 1 : 0;
+        if (s_ok) {
+            const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+            double UW[9], UWt[9];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) {
+                    double s1 = 0, s2 = 0;
+                    for (int q = 0; q < 3; q++) { s1 += U[i * 3 + q] * W[q * 3 + j]; s2 += U[i * 3 + q] * W[j * 3 + q]; }
+                    UW[i * 3 + j] = s1; UWt[i * 3 + j] = s2;
+                }
+            for (int cnd = 0; cnd < 4; cnd++) {
+                const double* M = (cnd & 1) ? UWt : UW;   // candidates: (R1,t) (R2,t) (R1,-t) (R2,-t)
+                double sgn = cnd >= 2 ? -1.0 : 1.0;
+                for (int i = 0; i < 3; i++) {
+                    for (int j = 0; j < 3; j++) {
+                        double s = 0;
+                        for (int q = 0; q < 3; q++) s += M[i * 3 + q] * Vm[j * 3 + q];
+                        s_P[cnd][i * 4 + j] = s;
+                    }
+                    s_P[cnd][i * 4 + 3] = sgn * U[i * 3 + 2];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (tid == 0) {
+            a.d_n_points[pair] = 0;
+            if (pose) for (int j = 0; j < 12; j++) pose[j] = __longlong_as_double(0x7FF8000000000000ll);
+        }
+        return;
+    }
+    // ---- final RANSAC mask + cheirality vote (recoverPose: depth in (0, 50) in both cameras)
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const double dist = 50.0;
+    int good[4] = {0, 0, 0, 0};
+    unsigned char cmask[(2048 + TV_BLOCK - 1) / TV_BLOCK * 2];  // per-thread bits for up to 4096 points
+    double E[9];
+    for (int j = 0; j < 9; j++) E[j] = s_E[j];
+    int slot = 0;
+    for (int i = tid; i < m; i += TV_BLOCK, slot++) {
+        double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
+        unsigned bits = 0;
+        if (sampson(E, x1, y1, x2, y2) <= thr2) {
+            for (int cnd = 0; cnd < 4; cnd++) {
+                double Pc[12], X[4];
+                for (int j = 0; j < 12; j++) Pc[j] = s_P[cnd][j];
+                dlt_point(P0, Pc, x1, y1, x2, y2, X);
+                bool ok = X[2] * X[3] > 0;
+                double iw = 1.0 / X[3];
+                double qx = X[0] * iw, qy = X[1] * iw, qz = X[2] * iw;
+                ok = ok && qz < dist;
+                double z2 = Pc[8] * qx + Pc[9] * qy + Pc[10] * qz + Pc[11];
+                ok = ok && z2 > 0 && z2 < dist;
+                if (ok) { bits |= 1u << cnd; good[cnd]++; }
+            }
+            bits |= 16u;
+            if (ran_out) ran_out[qidx[i]] = 1;
+        }
+        if (slot < (int)sizeof(cmask)) cmask[slot] = (unsigned char)bits;
+    }
+    int g[4];
+    for (int cnd = 0; cnd < 4; cnd++) g[cnd] = block_sum_i(good[cnd], s_redi);
+    if (tid == 0) {
+        int win;
+        if (g[0] >= g[1] && g[0] >= g[2] && g[0] >= g[3]) win = 0;
+        else if (g[1] >= g[0] && g[1] >= g[2] && g[1] >= g[3]) win = 1;
+        else if (g[2] >= g[0] && g[2] >= g[1] && g[2] >= g[3]) win = 2;
+        else win = 3;
+        s_win = win;
+        // pixel-space projection matrices P1 = K [I|0], P2 = K [R|t]  (utils.py:137-160)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 4; j++) {
+                double s1 = 0, s2 = 0;
+                for (int q = 0; q < 3; q++) { s1 += a.K[i * 3 + q] * P0[q * 4 + j]; s2 += a.K[i * 3 + q] * s_P[win][q * 4 + j]; }
+                s_Ppix[0][i * 4 + j] = s1; s_Ppix[1][i * 4 + j] = s2;
+            }
+        if (pose) {
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) pose[i * 3 + j] = s_P[win][i * 4 + j];
+                pose[9 + i] = s_P[win][i * 4 + 3];
+            }
+        }
+        if (a.d_E) for (int j = 0; j < 9; j++) a.d_E[(size_t)pair * 9 + j] = s_E[j];
+        a.d_n_points[pair] = g[win];
+    }
+    __syncthreads();
+    const int win = s_win;
+    double Pa[12], Pb[12];
+    for (int j = 0; j < 12; j++) { Pa[j] = s_Ppix[0][j]; Pb[j] = s_Ppix[1][j]; }
+    slot = 0;
+    for (int i = tid; i < m; i += TV_BLOCK, slot++) {
+        unsigned bits = slot < (int)sizeof(cmask) ? cmask[slot] : 0;
+        if (!((bits >> win) & 1u)) continue;
+        double X[4];
+        dlt_point(Pa, Pb, (double)px[4 * i], (double)px[4 * i + 1], (double)px[4 * i + 2], (double)px[4 * i + 3], X);
+        float xf = (float)X[0], yf = (float)X[1], zf = (float)X[2], wf = (float)X[3];
+        int o = qidx[i];
+        Xout[3 * o] = xf / wf; Xout[3 * o + 1] = yf / wf; Xout[3 * o + 2] = zf / wf;
+        if (inl_out) inl_out[o] = 1;
+    }
+}
+
+struct TriArgs { double P1[12], P2[12]; };
+
+__global__ void k_triangulate(TriArgs t, const float* __restrict__ p1, const float* __restrict__ p2, int n, float* __restrict__ X4) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double X[4];
+    dlt_point(t.P1, t.P2, (double)p1[2 * i], (double)p1[2 * i + 1], (double)p2[2 * i], (double)p2[2 * i + 1], X);
+    for (int k = 0; k < 4; k++) X4[4 * i + k] = (float)X[k];
+}
+
+int triangulate_launch(mo_ctx* c, const double* P1, const double* P2, const float* d_p1, const float* d_p2, int n, float* d_X4) {
+    if (n <= 0) return MO_OK;
+    TriArgs t;
+    for (int i = 0; i < 12; i++) { t.P1[i] = P1[i]; t.P2[i] = P2[i]; }
+    hipLaunchKernelGGL(k_triangulate, dim3((n + 127) / 128), dim3(128), 0, c->stream, t, d_p1, d_p2, n, d_X4);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
+    if (a.n_pairs <= 0) return MO_OK;
+    if (a.cap > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "two-view stage supports at most 4096 correspondences per pair");
+    if (a.n_hyp < 1 || a.n_hyp > (1 << 20)) return mo_fail(c, MO_ERR_ARG, "n_hyp out of range");
+    size_t need = twoview_workspace_bytes(a.n_pairs, a.cap, a.n_hyp);
+    int rc = mo_reserve(c, c->d_tv, c->tv_bytes, need);
+    if (rc) return rc;
+    TvWork w = carve(c->d_tv, a.n_pairs, a.cap, a.n_hyp);
+    hipLaunchKernelGGL(k_tv_prep, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+    hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+    hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}

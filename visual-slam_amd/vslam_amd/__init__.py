@@ -1,0 +1,269 @@
+"""vslam_amd -- ctypes binding of libvslam_amd.so (include/vslam_amd.h), the MI355X-native ORB front-end.
+
+This module is plumbing only: it loads the HIP library that sits next to this package, declares the C-ABI
+signatures and turns status codes into exceptions.  There is NO CPU implementation behind it: without the
+built library, or without a HIP device, every call fails loudly (NativeUnavailable).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "libvslam_amd.so")
+
+MO_OK, MO_ERR_ARG, MO_ERR_HIP, MO_ERR_CAPACITY, MO_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+ORDER_LIBSTDCXX, ORDER_MSVC = 0, 1
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                     ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+
+class NativeUnavailable(RuntimeError):
+    pass
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvslam_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("edge_threshold", C.c_int32), ("first_level", C.c_int32), ("wta_k", C.c_int32),
+                ("score_type", C.c_int32), ("patch_size", C.c_int32), ("fast_threshold", C.c_int32),
+                ("select_order", C.c_int32)]
+
+
+class BatchIO(C.Structure):
+    _fields_ = [("d_gray", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("batch", C.c_int32), ("cap", C.c_int32),
+                ("ratio", C.c_double), ("K", C.c_double * 9), ("thr_px", C.c_double), ("n_hyp", C.c_int32),
+                ("seed", C.c_uint64),
+                ("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("d_counts", C.c_void_p), ("d_match_idx", C.c_void_p),
+                ("d_match_dist", C.c_void_p), ("d_match_pass", C.c_void_p), ("d_pose", C.c_void_p),
+                ("d_points", C.c_void_p), ("d_n_points", C.c_void_p)]
+
+
+# every symbol include/vslam_amd.h declares: name -> (restype, argtypes)
+_vp, _i, _d = C.c_void_p, C.c_int, C.c_double
+SIGNATURES = {
+    "mo_create": (_vp, [_i, _i, _i, _i]),
+    "mo_destroy": (None, [_vp]),
+    "mo_last_error": (C.c_char_p, [_vp]),
+    "mo_set_stream": (_i, [_vp, _vp]),
+    "mo_sync": (_i, [_vp]),
+    "mo_device_count": (_i, []),
+    "mo_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mo_orb_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "mo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "mo_init_two_view": (_i, [_vp, _vp, _vp, _i, _vp, _d, _d, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mo_triangulate_points": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mo_dev_frontend_batch": (_i, [_vp, _vp, _vp]),
+    "mo_dev_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "mo_dev_match_pairs": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
+    "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mo_dbg_fast_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "mo_dbg_retain_best": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libvslam_amd.so and declare all signatures (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeUnavailable(
+            "%s is missing: build it with `make -C visual-slam_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load_library().mo_device_count())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def orb_params(nfeatures=2000, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=7,
+               select_order=ORDER_LIBSTDCXX):
+    return OrbParams(int(nfeatures), float(scale_factor), int(nlevels), int(edge_threshold), 0, 2, 0, 31,
+                     int(fast_threshold), int(select_order))
+
+
+class Context:
+    """Owns one mo_ctx (one GPU, one stream).  Thread-compatible, like the reference's single-threaded use."""
+
+    def __init__(self, device=0, max_w=2048, max_h=2048, max_batch=1):
+        self.lib = load_library()
+        if self.lib.mo_device_count() <= 0:
+            raise NativeUnavailable("no HIP device visible: the MI355X front-end has no CPU fallback")
+        self.h = self.lib.mo_create(int(device), int(max_w), int(max_h), int(max_batch))
+        if not self.h:
+            raise NativeUnavailable(self.lib.mo_last_error(None).decode())
+        self.device = device
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != MO_OK:
+            raise NativeError(rc, self.lib.mo_last_error(self.h).decode())
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.mo_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def sync(self):
+        self._check(self.lib.mo_sync(self.h))
+
+    def stage_times(self):
+        names = C.POINTER(C.c_char_p)()
+        ms = (C.c_float * 32)()
+        n = self.lib.mo_stage_times(self.h, C.byref(names), ms, 32)
+        if n < 0:
+            self._check(n)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+    # ---- host API ---------------------------------------------------------------------------------------
+    def orb_detect_compute(self, images, prm, want_desc=True, cap=None):
+        """images: (H,W) / (H,W,3) / (B,H,W) / (B,H,W,3) uint8 -> list of (kps structured array, desc or None)"""
+        a = np.ascontiguousarray(images, dtype=np.uint8)
+        if a.ndim == 2:
+            a = a[None]
+        elif a.ndim == 3 and a.shape[-1] == 3 and images.ndim == 3:
+            a = a[None]
+        ch = 3 if a.ndim == 4 else 1
+        b, h, w = a.shape[0], a.shape[1], a.shape[2]
+        cap = int(cap or (prm.nfeatures + 1024))
+        while True:
+            kps = np.zeros((b, cap), KP_DTYPE)
+            desc = np.zeros((b, cap, 32), np.uint8) if want_desc else None
+            counts = np.zeros(b, np.int32)
+            rc = self.lib.mo_orb_detect_compute(self.h, C.byref(prm), _ptr(a), w, h, w * ch, ch, b, _ptr(kps),
+                                                _ptr(desc), cap, _ptr(counts))
+            if rc == MO_ERR_CAPACITY and counts.max() > cap:
+                cap = int(counts.max())
+                continue
+            self._check(rc)
+            break
+        out = []
+        for f in range(b):
+            n = int(counts[f])
+            out.append((kps[f, :n].copy(), desc[f, :n].copy() if want_desc and n else None))
+        return out
+
+    def orb_compute(self, image, prm, kps_in):
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        ch = 3 if a.ndim == 3 else 1
+        h, w = a.shape[0], a.shape[1]
+        k = np.ascontiguousarray(kps_in, KP_DTYPE)
+        n = len(k)
+        kept = np.zeros(max(n, 1), np.int32)
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        n_out = C.c_int(0)
+        self._check(self.lib.mo_orb_compute(self.h, C.byref(prm), _ptr(a), w, h, w * ch, ch, _ptr(k), n, _ptr(kept),
+                                            _ptr(desc), C.byref(n_out)))
+        return kept[:n_out.value].copy(), desc[:n_out.value].copy()
+
+    def match_knn2_ratio(self, q, t, ratio=None):
+        """q (nq,32) or (B,nq,32), t likewise -> idx (..,nq,2) i32, dist (..,nq,2) i32, pass (..,nq) bool"""
+        q = np.ascontiguousarray(q, np.uint8)
+        t = np.ascontiguousarray(t, np.uint8)
+        single = q.ndim == 2
+        if single:
+            q, t = q[None], t[None]
+        b, nq, nt = q.shape[0], q.shape[1], t.shape[1]
+        idx = np.full((b, nq, 2), -1, np.int32)
+        dist = np.full((b, nq, 2), np.iinfo(np.int32).max, np.int32)
+        ps = np.zeros((b, nq), np.uint8)
+        r = C.c_double(float(ratio)) if ratio is not None else None
+        self._check(self.lib.mo_match_knn2_ratio(self.h, _ptr(q), nq, _ptr(t), nt, C.byref(r) if r is not None else None,
+                                                 b, _ptr(idx), _ptr(dist), _ptr(ps)))
+        if single:
+            return idx[0], dist[0], ps[0].astype(bool)
+        return idx, dist, ps.astype(bool)
+
+    def init_two_view(self, p1, p2, K, thr_px=3.0, prob=0.999, n_hyp=4096, seed=4096):
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        m = len(p1)
+        R = np.zeros(9); t = np.zeros(3); E = np.zeros(9)
+        ran = np.zeros(max(m, 1), np.uint8); inl = np.zeros(max(m, 1), np.uint8)
+        X = np.zeros((max(m, 1), 3), np.float32)
+        ng = C.c_int(0)
+        self._check(self.lib.mo_init_two_view(self.h, _ptr(p1), _ptr(p2), m, _ptr(Kc), float(thr_px), float(prob),
+                                              int(n_hyp), C.c_uint64(int(seed)), _ptr(R), _ptr(t), _ptr(E), _ptr(ran),
+                                              _ptr(inl), _ptr(X), C.byref(ng)))
+        return dict(R=R.reshape(3, 3), t=t.reshape(3, 1), E=E.reshape(3, 3), ransac_mask=ran[:m].astype(bool),
+                    pose_mask=inl[:m].astype(bool), X=X[:m], n_good=ng.value)
+
+    def triangulate_points(self, P1, P2, p1, p2):
+        P1 = np.ascontiguousarray(P1, np.float64).reshape(12)
+        P2 = np.ascontiguousarray(P2, np.float64).reshape(12)
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        n = len(p1)
+        X4 = np.zeros((max(n, 1), 4), np.float32)
+        self._check(self.lib.mo_triangulate_points(self.h, _ptr(P1), _ptr(P2), _ptr(p1), _ptr(p2), n, _ptr(X4)))
+        return X4[:n]
+
+    # ---- probes --------------------------------------------------------------------------------------------
+    def dbg_pyramid_level(self, gray, prm, level, blurred=False):
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        out = np.zeros(h * w, np.uint8)
+        lw, lh = C.c_int(0), C.c_int(0)
+        self._check(self.lib.mo_dbg_pyramid_level(self.h, C.byref(prm), _ptr(g), w, h, level, int(blurred), _ptr(out),
+                                                  C.byref(lw), C.byref(lh)))
+        return out[:lw.value * lh.value].reshape(lh.value, lw.value).copy()
+
+    def dbg_fast_level(self, gray, prm, level):
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        cap = w * h // 4 + 16
+        out = np.zeros((cap, 3), np.int32)
+        n = C.c_int(0)
+        self._check(self.lib.mo_dbg_fast_level(self.h, C.byref(prm), _ptr(g), w, h, level, _ptr(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def dbg_retain_best(self, resp, n_points, order):
+        r = np.ascontiguousarray(resp, np.float32)
+        out = np.zeros(max(len(r), 1), np.int32)
+        n = C.c_int(0)
+        self._check(self.lib.mo_dbg_retain_best(self.h, _ptr(r), len(r), int(n_points), int(order), _ptr(out), C.byref(n)))
+        return out[:n.value].copy()
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context used by the drop-in orbslam2 classes (device from VSLAM_AMD_DEVICE / LOCAL_RANK)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("VSLAM_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(device=dev, max_w=4095, max_h=4095, max_batch=1)
+    return _default_ctx
