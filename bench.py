@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec (extract + match + pose) at 640x480, 2000 ORB, on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic frames already resident in HBM:
+extract every frame (8-level pyramid, FAST-9, retainBest x2, Harris, IC angle, blur, rBRIEF), match every
+consecutive frame pair (brute-force Hamming 2-NN + ratio test), two-view pose + map points per pair
+(8-point E RANSAC over 4096 hypotheses, pose recovery, DLT), then the final map-point gather to rank 0.
+
+Workload at N=1: BASELINE.json configs[2] "batch of 256 synthetic 640x480 frames, extract+match pipeline"
+plus the two-view stage of configs[3] on every pair.  N>1: frames are independent, so the global frame
+sequence is sharded contiguously (weak scaling: 256 frames per rank); each rank re-extracts the one frame
+preceding its shard (halo) instead of receiving it, and the only collective is the RCCL gather of map points.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via torch.distributed.run (one rank per GPU).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "visual-slam_amd"))
+
+W, H, NFEAT, CAP = 640, 480, 2000, 2048
+N_HYP = 4096
+PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
+
+# algorithmic bytes per frame of each extraction stage (stage-materialised model)
+STAGE_BYTES = {
+    "pyramid": 926546 + 643332,      # resize reads L0..6 + writes L1..7
+    "fast_nms": 950532,              # FAST reads L0..7
+    "select_harris": 0,              # candidate lists only (latency-bound replay), priced at 0 algorithmic bytes
+    "blur": 950532 + 950532,         # reads + writes of the blurred pyramid
+    "angle_rbrief": 950532 + 120000, # descriptor reads + keypoint/descriptor outputs
+    "match_knn2_ratio": 162000,      # per PAIR: 2 x 64000 B descriptors in + 34000 B out
+    "two_view": 32000,               # per PAIR: correspondences in (<= 2000 x 16 B)
+}
+
+
+def make_frames(torch, device, first, count, seed=20250523):
+    """Frames [first, first+count) of the global synthetic sequence: a sliding 640x480 window over a seeded
+    textured canvas (2 px / frame pan with a slow vertical drift) plus per-frame N(0,2) noise."""
+    from tests.helpers import synthetic_frame
+    span = 1024
+    canvas = np.concatenate([synthetic_frame(seed + k, W, H + 64) for k in range((span + W) // W + 2)], axis=1)
+    cv = torch.from_numpy(canvas).to(device=device, dtype=torch.float32)
+    out = torch.empty((count, H, W), dtype=torch.uint8, device=device)
+    for i in range(count):
+        g = first + i
+        x0 = (2 * g) % span
+        y0 = 16 + int(round(12 * np.sin(g / 40.0)))
+        gen = torch.Generator(device=device)
+        gen.manual_seed(seed * 1000003 + g)
+        fr = cv[y0:y0 + H, x0:x0 + W] + 2.0 * torch.randn((H, W), generator=gen, device=device)
+        out[i] = fr.round().clamp_(0, 255).to(torch.uint8)
+    return out
+
+
+def cpu_baseline(frames_u8, n_frames, K):
+    """The CPU oracle (own C++/numpy restatement; cv2 is not installed) on a bounded sample, 1 core."""
+    from oracle import geom_oracle as G
+    from oracle import orb_oracle as O
+    O.lib().orc_set_variant(0, 0)
+    prm = O.params(nfeatures=NFEAT)
+    t0 = time.perf_counter()
+    feats = [O.detect_and_compute(frames_u8[i], prm) for i in range(n_frames)]
+    t1 = time.perf_counter()
+    matches = []
+    for i in range(n_frames - 1):
+        idx, dist = O.match_knn2(feats[i][1], feats[i + 1][1])
+        matches.append((idx, O.ratio_test(idx, dist, 0.75)))
+    t2 = time.perf_counter()
+    n_pose = min(2, n_frames - 1)
+    for i in range(n_pose):
+        idx, keep = matches[i]
+        p1 = np.stack([feats[i][0]["x"], feats[i][0]["y"]], 1)[keep]
+        p2 = np.stack([feats[i + 1][0]["x"], feats[i + 1][0]["y"]], 1)[idx[keep, 0]]
+        G.init_two_view(p1, p2, K, thr_px=3.0, n_hyp=N_HYP, seed=4096)
+    t3 = time.perf_counter()
+    per_frame = (t1 - t0) / n_frames + (t2 - t1) / max(n_frames - 1, 1) + (t3 - t2) / max(n_pose, 1)
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d frames extract (%.3f s), %d pairs match (%.3f s), %d pairs two-view numpy f64 (%.3f s); "
+                      "own CPU restatement, cv2 unavailable" % (n_frames, t1 - t0, n_frames - 1, t2 - t1, n_pose, t3 - t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per rank per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=24)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import vslam_amd as V
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP front-end has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    from vslam_amd.sharding import gather_map_points, shard
+    B = args.batch
+    first, nb, n_pairs, _ = shard(rank, world, B)   # rank > 0 re-extracts the frame preceding its shard (halo)
+    frames = make_frames(torch, dev, first, nb)
+    K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])  # configs/monocular.yaml:3
+
+    ctx = V.Context(device=local, max_w=W, max_h=H, max_batch=nb)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    prm = V.orb_params(nfeatures=NFEAT, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=7,
+                       select_order=V.ORDER_LIBSTDCXX)
+    kps = torch.zeros((nb, CAP, 7), dtype=torch.float32, device=dev)   # 28-byte mo_keypoint records
+    desc = torch.zeros((nb, CAP, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(nb, dtype=torch.int32, device=dev)
+    midx = torch.zeros((nb - 1, CAP, 2), dtype=torch.int32, device=dev)
+    mdist = torch.zeros((nb - 1, CAP, 2), dtype=torch.int32, device=dev)
+    mpass = torch.zeros((nb - 1, CAP), dtype=torch.uint8, device=dev)
+    pose = torch.zeros((nb - 1, 12), dtype=torch.float64, device=dev)
+    pts = torch.zeros((B, CAP, 3), dtype=torch.float32, device=dev)  # rank 0 fills B-1 pairs, the others B
+    npts = torch.zeros(nb - 1, dtype=torch.int32, device=dev)
+    io = V.BatchIO()
+    io.d_gray = frames.data_ptr(); io.w = W; io.h = H; io.batch = nb; io.cap = CAP
+    io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = N_HYP; io.seed = 4096
+    for i in range(9):
+        io.K[i] = float(K.reshape(9)[i])
+    io.d_kps = kps.data_ptr(); io.d_desc = desc.data_ptr(); io.d_counts = counts.data_ptr()
+    io.d_match_idx = midx.data_ptr(); io.d_match_dist = mdist.data_ptr(); io.d_match_pass = mpass.data_ptr()
+    io.d_pose = pose.data_ptr(); io.d_points = pts.data_ptr(); io.d_n_points = npts.data_ptr()
+
+    stage_acc = {}
+
+    def step(collect):
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        if world > 1:  # final map-point gather (the only collective on the path)
+            gather_map_points(pts, n_pairs, dst=0)
+        if collect:
+            for name, ms in ctx.stage_times():
+                stage_acc[name] = stage_acc.get(name, 0.0) + ms
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+
+    if rank == 0:
+        total_frames = world * B * args.steps
+        ms_step = elapsed / args.steps * 1e3
+        value = total_frames / elapsed
+        cnt = counts.cpu().numpy()
+        npt = npts.cpu().numpy()
+        # roofline of the dominant kernel (largest share of device time), algorithmic bytes / measured duration
+        per_stage = {k: v / args.steps for k, v in stage_acc.items()}
+        dom = max(per_stage, key=per_stage.get)
+        units = (nb - 1) if dom in ("match_knn2_ratio", "two_view") else nb
+        alg_bytes = STAGE_BYTES.get(dom, 0) * units
+        achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
+        total_alg = sum(STAGE_BYTES.get(k, 0) * ((nb - 1) if k in ("match_knn2_ratio", "two_view") else nb) for k in per_stage)
+        out = {
+            "metric": "frames/sec (extract+match+pose) at 640x480, 2000 ORB",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "batch of %d synthetic 640x480 frames per GPU: ORB extract (2000 feat, 8 levels, FAST-7) "
+                                   "+ BF-Hamming 2-NN ratio 0.75 on consecutive pairs + 8-pt E RANSAC (%d hyp) pose/DLT per pair"
+                                   % (B, N_HYP),
+                       "frames_per_gpu": B, "n_features": NFEAT, "hypotheses": N_HYP,
+                       "keypoints_per_frame_mean": float(cnt.mean()), "map_points_per_pair_mean": float(npt.mean()),
+                       "parallelism": "frame-sharded x%d, RCCL gather of map points" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
+                         "kernel_ms": round(per_stage[dom], 4),
+                         "pipeline_achieved": round(total_alg / (ms_step * 1e-3) / 1e9, 2),
+                         "note": "algorithmic bytes (SURVEY 8d) of the dominant stage / its hipEvent time; the path is "
+                                 "integer-VALU / latency bound, far from the HBM roof (see DESIGN.md)"},
+            "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames].cpu().numpy(), args.cpu_frames, K)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+"""oracle/geom_oracle.py -- TEST INFRASTRUCTURE ONLY (CPU restatement of the two-view stage, numpy f64).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+What it restates: the geometry behind the reference's MapInitializer.initialize
+  /root/reference/src/orbslam2/initializer.py:79   calculate_essential_matrix(p1, p2, K, threshold=3.0)
+  /root/reference/src/orbslam2/utils.py:120-126    cv2.findEssentialMat(..., RANSAC, prob, threshold)
+  /root/reference/src/orbslam2/utils.py:129-134    cv2.recoverPose(E, p1, p2, K, mask)
+  /root/reference/src/orbslam2/utils.py:56-70      cv2.triangulatePoints + divide by w
+The arithmetic lives in the absent, unpinned cv2 wheel.  cv2.findEssentialMat is a sequential 5-point RANSAC;
+north_star prescribes an 8-point RANSAC over a fixed number of hypotheses scored in parallel, so this oracle
+restates THAT algorithm (same counter-based sampling as the HIP kernels, independent linear algebra: numpy
+SVDs instead of the kernels' Gauss-Jordan / Jacobi solvers).  PARITY UNPINNED against cv2: no fixture of the
+reference holds E, R, t or 3-D points; results are checked against synthetic ground truth and against the
+HIP path at 1e-4 relative.  recoverPose and triangulatePoints follow OpenCV's published algorithm (SVD
+decomposition, W matrix, cheirality vote with depth in (0, 50), per-point 4x4 DLT null vector).
+"""
+import numpy as np
+
+M64 = (1 << 64) - 1
+
+
+def _splitmix64(state):
+    state = (state + 0x9E3779B97F4A7C15) & M64
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return state, z ^ (z >> 31)
+
+
+def sample8(seed, h, m, pair=0):
+    """8 distinct correspondence indices of hypothesis h (same stream as twoview_kernels.hip sample8)."""
+    seed = (seed + pair * 0x632BE59BD9B4E019) & M64
+    s = (seed + (h + 1) * 0xD1B54A32D192ED03) & M64
+    idx = []
+    while len(idx) < 8:
+        s, r = _splitmix64(s)
+        c = r % m
+        if c not in idx:
+            idx.append(c)
+    return idx
+
+
+def normalise(p, K):
+    p = np.asarray(p, np.float32).astype(np.float64)
+    return np.stack([(p[:, 0] - K[0, 2]) / K[0, 0], (p[:, 1] - K[1, 2]) / K[1, 1]], axis=1)
+
+
+def _design(x1, x2):
+    return np.stack([x2[:, 0] * x1[:, 0], x2[:, 0] * x1[:, 1], x2[:, 0], x2[:, 1] * x1[:, 0], x2[:, 1] * x1[:, 1],
+                     x2[:, 1], x1[:, 0], x1[:, 1], np.ones(len(x1))], axis=1)
+
+
+def project_essential(E):
+    U, s, Vt = np.linalg.svd(E)
+    return U @ np.diag([1.0, 1.0, 0.0]) @ Vt
+
+
+def sampson(E, x1, x2):
+    """E (...,3,3), x1/x2 (M,2) -> (..., M) Sampson distance x2^T E x1 squared over the gradient norm"""
+    h1 = np.concatenate([x1, np.ones((len(x1), 1))], axis=1)
+    h2 = np.concatenate([x2, np.ones((len(x2), 1))], axis=1)
+    Ex1 = np.einsum("...ij,mj->...mi", E, h1)
+    Etx2 = np.einsum("...ji,mj->...mi", E, h2)
+    num = np.einsum("...mi,mi->...m", Ex1, h2)
+    den = Ex1[..., 0] ** 2 + Ex1[..., 1] ** 2 + Etx2[..., 0] ** 2 + Etx2[..., 1] ** 2
+    return num * num / den
+
+
+def find_essential_ransac8(p1, p2, K, thr_px=3.0, n_hyp=4096, seed=4096, pair=0, chunk=512):
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    x1, x2 = normalise(p1, K), normalise(p2, K)
+    m = len(x1)
+    if m < 8:
+        return None, np.zeros(m, bool)
+    thr = thr_px / ((K[0, 0] + K[1, 1]) / 2.0)
+    thr2 = thr * thr
+    samples = np.array([sample8(seed, h, m, pair) for h in range(n_hyp)])
+    A = _design(x1[samples.ravel()], x2[samples.ravel()]).reshape(n_hyp, 8, 9)
+    _, _, Vt = np.linalg.svd(A)
+    Es = Vt[:, -1, :].reshape(n_hyp, 3, 3)
+    U, s, Vt3 = np.linalg.svd(Es)
+    Es = U[:, :, :2] @ Vt3[:, :2, :]
+    # MSAC score: sum of Sampson distances truncated at thr^2 (a pure inlier count would prefer slightly
+    # perturbed models that catch more chance inliers); compared in float32, ties -> lowest hypothesis index
+    cost = np.full(n_hyp, np.inf, np.float32)
+    for a in range(0, n_hyp, chunk):
+        d = sampson(Es[a:a + chunk], x1, x2)
+        cost[a:a + chunk] = np.minimum(d, thr2).sum(axis=1).astype(np.float32)
+    hbest = int(np.argmin(cost))
+    E = Es[hbest]
+    n0 = int((sampson(E, x1, x2) <= thr2).sum())
+    if n0 < 8:
+        return None, np.zeros(m, bool)
+    # local optimisation: least-squares 8-point refits on an adaptively tightened consensus set.  The selection
+    # threshold follows a 3-sigma rule on the mean Sampson residual of the previous selection (clamped to
+    # [thr/64, thr]), so chance inliers of the loose RANSAC threshold do not bias the algebraic fit; a refit is
+    # only accepted while at least half of the original consensus is still selected.
+    lo2 = thr2 / 4096.0
+    d = sampson(E, x1, x2)
+    sel = d <= thr2
+    tau2 = min(max(9.0 * float(d[sel].sum()) / int(sel.sum()), lo2), thr2)
+    for _ in range(5):
+        d = sampson(E, x1, x2)
+        sel = d <= tau2
+        c = int(sel.sum())
+        if c < 8 or 2 * c < n0:
+            break
+        _, _, Vt = np.linalg.svd(_design(x1[sel], x2[sel]), full_matrices=False)
+        E = project_essential(Vt[-1].reshape(3, 3))
+        tau2 = min(max(9.0 * float(d[sel].sum()) / c, lo2), thr2)
+    mask = sampson(E, x1, x2) <= thr2
+    return E, mask
+
+
+def triangulate(P1, P2, a1, a2):
+    """cv2.triangulatePoints: per point the right singular vector of the smallest singular value -> (N,4) f64"""
+    n = len(a1)
+    A = np.empty((n, 4, 4))
+    A[:, 0] = a1[:, 0:1] * P1[2] - P1[0]
+    A[:, 1] = a1[:, 1:2] * P1[2] - P1[1]
+    A[:, 2] = a2[:, 0:1] * P2[2] - P2[0]
+    A[:, 3] = a2[:, 1:2] * P2[2] - P2[1]
+    _, _, Vt = np.linalg.svd(A)
+    return Vt[:, -1, :]
+
+
+def recover_pose(E, p1, p2, K, mask, dist=50.0):
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    x1, x2 = normalise(p1, K), normalise(p2, K)
+    U, _, Vt = np.linalg.svd(E)
+    if np.linalg.det(U) < 0:
+        U = -U
+    if np.linalg.det(Vt) < 0:
+        Vt = -Vt
+    W = np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]])
+    R1, R2, t = U @ W @ Vt, U @ W.T @ Vt, U[:, 2:3]
+    P0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    cands = [(R1, t), (R2, t), (R1, -t), (R2, -t)]
+    masks = []
+    for R, tt in cands:
+        P = np.hstack([R, tt])
+        Q = triangulate(P0, P, x1, x2)
+        ok = Q[:, 2] * Q[:, 3] > 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            q = Q[:, :3] / Q[:, 3:4]
+        ok &= q[:, 2] < dist
+        z2 = (P @ np.concatenate([q, np.ones((len(q), 1))], axis=1).T)[2]
+        ok &= (z2 > 0) & (z2 < dist)
+        masks.append(ok & mask)
+    good = [int(mk.sum()) for mk in masks]
+    if good[0] >= good[1] and good[0] >= good[2] and good[0] >= good[3]: w = 0
+    elif good[1] >= good[0] and good[1] >= good[2] and good[1] >= good[3]: w = 1
+    elif good[2] >= good[0] and good[2] >= good[1] and good[2] >= good[3]: w = 2
+    else: w = 3
+    return good[w], cands[w][0], cands[w][1], masks[w]
+
+
+def init_two_view(p1, p2, K, thr_px=3.0, n_hyp=4096, seed=4096, pair=0):
+    """-> dict(E, R, t, ransac_mask, pose_mask, X (M,3) f32 with NaN outside pose_mask, n_good)"""
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    p1 = np.asarray(p1, np.float32); p2 = np.asarray(p2, np.float32)
+    E, mask = find_essential_ransac8(p1, p2, K, thr_px, n_hyp, seed, pair)
+    if E is None:
+        return dict(E=None, R=None, t=None, ransac_mask=mask, pose_mask=mask, X=np.full((len(p1), 3), np.nan, np.float32), n_good=0)
+    n_good, R, t, pmask = recover_pose(E, p1, p2, K, mask)
+    P1 = K @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = K @ np.hstack([R, t])
+    X = np.full((len(p1), 3), np.nan, np.float32)
+    if pmask.any():
+        X4 = triangulate(P1, P2, p1[pmask].astype(np.float64), p2[pmask].astype(np.float64)).astype(np.float32)
+        X[pmask] = X4[:, :3] / X4[:, 3:4]
+    return dict(E=E, R=R, t=t, ransac_mask=mask, pose_mask=pmask, X=X, n_good=n_good)
+
+
+def synthetic_two_view(seed=4096, n=2000, outlier_frac=0.3, K=None, w=640, h=480):
+    """seeded two-view problem with ground truth."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if K is None:
+        K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])
+    X = np.stack([rng.uniform(-4, 4, n), rng.uniform(-4, 4, n), rng.uniform(4, 12, n)], axis=1)
+    rv = np.array([0.02, -0.05, 0.01])
+    th = np.linalg.norm(rv)
+    k = rv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = np.array([1.0, 0.1, 0.05]); t /= np.linalg.norm(t)
+    x1 = (K @ X.T).T; p1 = x1[:, :2] / x1[:, 2:3]
+    Xc2 = (R @ X.T).T + t
+    x2 = (K @ Xc2.T).T; p2 = x2[:, :2] / x2[:, 2:3]
+    p1 = p1.astype(np.float32); p2 = p2.astype(np.float32)
+    out = rng.random(n) < outlier_frac
+    no = int(out.sum())
+    p2[out] = np.stack([rng.uniform(0, w, no), rng.uniform(0, h, no)], axis=1).astype(np.float32)
+    return dict(K=K, p1=p1, p2=p2, R=R, t=t.reshape(3, 1), X=X, outlier=out)

@@ -1,0 +1,69 @@
+"""CPU-side checks of the boundary: the library loads, exports every symbol include/vslam_amd.h declares,
+fails loudly without a GPU, and the host-side list logic of the drop-in classes behaves like the reference's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    import vslam_amd as V
+    lib = V.load_library()
+    hdr = open(os.path.join(ROOT, "include", "vslam_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(mo_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert names == set(V.SIGNATURES), names ^ set(V.SIGNATURES)
+
+
+def test_struct_layouts():
+    import ctypes as C
+    import vslam_amd as V
+    assert V.KP_DTYPE.itemsize == 28
+    assert C.sizeof(V.OrbParams) == 40
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
+def test_fails_loudly_without_gpu():
+    import vslam_amd as V
+    assert V.device_count() == 0
+    with pytest.raises(V.NativeUnavailable):
+        V.Context()
+    from orbslam2.extractor import ORBExtractor
+    with pytest.raises(V.NativeUnavailable):
+        ORBExtractor(n_features=100).detect_and_compute(np.zeros((480, 640), np.uint8))
+
+
+def test_matcher_host_logic():
+    from orbslam2.matcher import DescriptorMatcher
+    from orbslam2.types import DMatch, KeyPoint
+    m = DescriptorMatcher(ratio_threshold=0.8)
+    assert m.match(None, np.zeros((3, 32), np.uint8)) == []
+    assert m.match(np.zeros((0, 32), np.uint8), np.zeros((3, 32), np.uint8)) == []
+    with pytest.raises(ValueError):
+        DescriptorMatcher("sift")
+    kp1 = [KeyPoint(0, 0, 31), KeyPoint(10, 10, 31), KeyPoint(100, 100, 31)]
+    kp2 = [KeyPoint(3, 4, 31), KeyPoint(200, 10, 31), KeyPoint(101, 100, 31)]
+    ms = [DMatch(0, 0, 0, 10.0), DMatch(1, 1, 0, 30.0), DMatch(2, 2, 0, 20.0)]
+    kept = m.filter_matches_by_geometric_distance(kp1, kp2, ms, 0.02, (480, 640))  # limit 11.2 px
+    assert [k.queryIdx for k in kept] == [0, 2]
+    by_d = m.filter_matches_by_distance(ms)  # median 20 -> threshold 40, sorted by distance
+    assert [k.distance for k in by_d] == [10.0, 20.0, 30.0]
+    assert [k.distance for k in m.filter_matches_by_distance(ms, 25.0)] == [10.0, 20.0]
+    assert m.filter_matches_by_distance([]) == []
+
+
+def test_initializer_guards():
+    from orbslam2.initializer import MapInitializer
+    from orbslam2.utils import compute_projection_matrix, convert_to_3d_points
+    ini = MapInitializer(np.eye(3), min_matches=10)
+    assert ini.initialize([], None, None, None) == (False, None, None, None, None)
+    P = compute_projection_matrix(np.eye(3), np.array([1.0, 2.0, 3.0]), np.diag([2.0, 2.0, 1.0]))
+    assert P.shape == (3, 4) and np.allclose(P[:, 3], [2, 4, 3])
+    X = convert_to_3d_points(np.array([[2.0, 4], [4, 8], [6, 12], [2, 4]], np.float32))
+    assert np.allclose(X, [[1, 2, 3], [1, 2, 3]])

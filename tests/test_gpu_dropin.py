@@ -1,0 +1,151 @@
+"""GPU: the drop-in orbslam2 classes driven like the reference's Tracker / tests drive them, and the batched
+device-resident mode against the host API."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import synthetic_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair():
+    a = synthetic_frame(20250523)
+    big = np.concatenate([a, synthetic_frame(20250524)], axis=1)
+    return a, np.ascontiguousarray(big[:, 6:646])  # second view = 6 px pan
+
+
+def test_extractor_matcher_like_test_matcher_py():
+    """reference src/tests/test_matcher.py:32-38,75-79: ORBExtractor(...5 args), detect_and_compute x2, match(ratio)."""
+    from oracle import orb_oracle as O
+    from orbslam2.extractor import ORBExtractor
+    from orbslam2.matcher import DescriptorMatcher
+    a, b = _pair()
+    ex = ORBExtractor(n_features=2000, scale_factor=1.2, n_levels=8, ini_threshold=20, min_threshold=7)
+    kp1, d1 = ex.detect_and_compute(a)
+    kp2, d2 = ex.detect_and_compute(b)
+    assert isinstance(kp1, tuple) and d1.shape == (len(kp1), 32) and d1.dtype == np.uint8
+    m = DescriptorMatcher(matcher_type='bruteforce-hamming', ratio_threshold=0.85)
+    good = m.match(d1, d2, ratio_test=True)
+    assert len(good) > 500
+    # same list as the oracle's knn + ratio loop, in query order
+    O.lib().orc_set_variant(0, 0)
+    idx, dist = O.match_knn2(d1, d2)
+    keep = O.ratio_test(idx, dist, 0.85)
+    exp = [(q, int(idx[q, 0]), float(dist[q, 0])) for q in np.nonzero(keep)[0]]
+    assert [(g.queryIdx, g.trainIdx, g.distance) for g in good] == exp
+    assert all(g.imgIdx == 0 for g in good)
+    assert len(m.match(d1, d2, ratio_test=False)) == len(kp1)
+    # colour input is converted on the device
+    kpc, dc = ex.detect_and_compute(np.repeat(a[:, :, None], 3, axis=2))
+    assert len(kpc) == len(kp1)
+    knn = m.matcher.knnMatch(d1[:5], d2, k=2)
+    assert len(knn) == 5 and all(len(r) == 2 for r in knn)
+
+
+def test_compute_keeps_reference_quirk():
+    """extractor.py:83: compute returns the ORIGINAL keypoints next to cv2's (possibly fewer) descriptor rows."""
+    from orbslam2.extractor import ORBExtractor
+    from orbslam2.types import KeyPoint
+    a, _ = _pair()
+    ex = ORBExtractor()
+    kps = [KeyPoint(100.0, 100.0, 31), KeyPoint(5.0, 5.0, 31), KeyPoint(320.5, 240.5, 31)]
+    out_kps, desc = ex.compute(a, kps)
+    assert out_kps is kps and desc.shape == (2, 32)
+    with pytest.raises(NotImplementedError):
+        ex.extract_features(a)  # distributed=True default -> grid Shi-Tomasi, next scope row
+    k2, d2 = ex.extract_features(a, distributed=False)
+    assert len(k2) > 1500
+
+
+def test_map_initializer_like_test_map_initializer_py():
+    """reference src/tests/test_map_initializer.py:84-115: structural assertions of the only real pytest test,
+    here on a synthetic two-view scene with known geometry so R, t are also checked."""
+    from oracle import geom_oracle as G
+    from orbslam2.initializer import MapInitializer
+    from orbslam2.types import DMatch, KeyPoint
+    s = G.synthetic_two_view(seed=21, n=800, outlier_frac=0.2)
+    kp1 = [KeyPoint(float(x), float(y), 31) for x, y in s["p1"]]
+    kp2 = [KeyPoint(float(x), float(y), 31) for x, y in s["p2"]]
+
+    class FixedMatcher:  # the matcher is an argument of initialize(); identity correspondences
+        def match(self, d1, d2):
+            return [DMatch(i, i, 0, 10.0) for i in range(len(kp1))]
+
+    ini = MapInitializer(s["K"], min_matches=10)
+    img = np.zeros((480, 640), np.uint8)
+    assert ini.initialize(kp2, np.zeros((800, 32), np.uint8), FixedMatcher(), img)[0] is False  # no first frame yet
+    ini.set_first_frame(kp1, np.zeros((800, 32), np.uint8), img)
+    ok, R, t, pts, matches = ini.initialize(kp2, np.zeros((800, 32), np.uint8), FixedMatcher(), img)
+    assert ok is True and R.shape == (3, 3) and t.shape == (3, 1)
+    assert len(pts) >= 20 and len(matches) >= 50 and len(pts) == len(matches)
+    assert np.linalg.norm(R - s["R"]) < 1e-4 and np.linalg.norm(t - s["t"]) < 1e-4
+    p = pts[0]
+    assert set(p) == {"position", "color", "keypoint_references", "observed_frames"}
+    assert p["observed_frames"] == [0, 1] and p["position"].shape == (3,)
+    q = p["keypoint_references"][0]
+    assert np.linalg.norm(p["position"] - s["X"][q]) / np.linalg.norm(s["X"][q]) < 1e-4
+    assert ini.initialization_done and ini.current_frame_keypoints is kp2
+
+
+def test_batched_device_mode_equals_host_api():
+    """mo_dev_frontend_batch on frames resident in HBM == per-call host API (extract, match, pose)."""
+    import torch
+    import vslam_amd as V
+    nb, cap = 4, 2048
+    base = np.concatenate([synthetic_frame(31), synthetic_frame(32)], axis=1)
+    frames = np.stack([np.ascontiguousarray(base[:, 4 * i:4 * i + 640]) for i in range(nb)])
+    dev = torch.device("cuda", 0)
+    ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    prm = V.orb_params(nfeatures=2000)
+    d_fr = torch.from_numpy(frames).to(dev)
+    kps = torch.zeros((nb, cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.zeros((nb, cap, 32), dtype=torch.uint8, device=dev)
+    counts = torch.zeros(nb, dtype=torch.int32, device=dev)
+    midx = torch.zeros((nb - 1, cap, 2), dtype=torch.int32, device=dev)
+    mdist = torch.zeros_like(midx)
+    mpass = torch.zeros((nb - 1, cap), dtype=torch.uint8, device=dev)
+    pose = torch.zeros((nb - 1, 12), dtype=torch.float64, device=dev)
+    pts = torch.zeros((nb - 1, cap, 3), dtype=torch.float32, device=dev)
+    npts = torch.zeros(nb - 1, dtype=torch.int32, device=dev)
+    K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])
+    io = V.BatchIO()
+    io.d_gray = d_fr.data_ptr(); io.w = 640; io.h = 480; io.batch = nb; io.cap = cap
+    io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = 512; io.seed = 4096
+    for i in range(9): io.K[i] = float(K.reshape(9)[i])
+    io.d_kps = kps.data_ptr(); io.d_desc = desc.data_ptr(); io.d_counts = counts.data_ptr()
+    io.d_match_idx = midx.data_ptr(); io.d_match_dist = mdist.data_ptr(); io.d_match_pass = mpass.data_ptr()
+    io.d_pose = pose.data_ptr(); io.d_points = pts.data_ptr(); io.d_n_points = npts.data_ptr()
+    ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+    torch.cuda.synchronize()
+    stages = dict(ctx.stage_times())
+    assert {"pyramid", "fast_nms", "select_harris", "blur", "angle_rbrief", "match_knn2_ratio", "two_view"} <= set(stages)
+    cn = counts.cpu().numpy()
+    host = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+    feats = [host.orb_detect_compute(frames[i], prm)[0] for i in range(nb)]
+    kp_np = kps.cpu().numpy().view(np.uint8).reshape(nb, cap, 28)
+    for i in range(nb):
+        n = len(feats[i][0])
+        assert cn[i] == n
+        assert np.array_equal(kp_np[i, :n].reshape(-1).view(V.KP_DTYPE), feats[i][0])
+        assert np.array_equal(desc[i, :n].cpu().numpy(), feats[i][1])
+    for i in range(nb - 1):
+        idx, dist, ps = host.match_knn2_ratio(feats[i][1], feats[i + 1][1], 0.75)
+        n = cn[i]
+        assert np.array_equal(midx[i, :n].cpu().numpy(), idx) and np.array_equal(mdist[i, :n].cpu().numpy(), dist)
+        assert np.array_equal(mpass[i, :n].cpu().numpy().astype(bool), ps)
+        p1 = np.stack([feats[i][0]["x"], feats[i][0]["y"]], 1)[ps]
+        p2 = np.stack([feats[i + 1][0]["x"], feats[i + 1][0]["y"]], 1)[idx[ps, 0]]
+        # per-pair sampling stream differs from the single-call API (seed is offset by the pair index), so compare
+        # through the geometry: both must describe the same epipolar geometry and map points
+        r = host.init_two_view(p1, p2, K, thr_px=3.0, n_hyp=512, seed=4096)
+        if i == 0:  # pair 0 uses exactly the same stream
+            assert np.allclose(pose[i].cpu().numpy()[:9].reshape(3, 3), r["R"], atol=1e-9)
+            assert int(npts[i].item()) == r["n_good"]
+            X = pts[i].cpu().numpy()
+            q_of = np.nonzero(ps)[0]
+            assert np.allclose(X[q_of[r["pose_mask"]]], r["X"][r["pose_mask"]], rtol=1e-5, atol=1e-6)
+            assert np.isnan(X[:n][~np.isin(np.arange(n), q_of[r["pose_mask"]])]).all()
+    ctx.close(); host.close()

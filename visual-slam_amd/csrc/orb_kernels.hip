@@ -304,8 +304,8 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_ACAP 8192   // u32 records in LDS (FAST pass)
-#define SEL_BCAP 3072   // u64 records in LDS (Harris pass)
+#define SEL_BUF_BYTES (96 * 1024)  // LDS record window: u32 FAST records, then u64 Harris records overlaid
+#define SEL_ACAP (64 * 1024 / 4)   // u32 records that fit the window (FAST pass)
 #define SEL_MAXSTRIPS 1024
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
                                                const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
                                                uint64_t* __restrict__ scratch, size_t scratch_stride,
                                                FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags) {
-    __shared__ uint32_t s_A[SEL_ACAP];
-    __shared__ uint64_t s_B[SEL_BCAP];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // SEL_BUF_BYTES
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
     __shared__ int s_n[2];
+    uint32_t* s_A = (uint32_t*)s_buf;
     const int L = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
@@ -409,7 +409,10 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
     }
     __syncthreads();
     const int N1 = s_n[0];
-    const bool b_lds = N1 <= SEL_BCAP;
+    // the Harris records go behind the surviving FAST records when both fit the window
+    const int b_off = a_lds ? ((N1 * 4 + 7) & ~7) : 0;
+    const bool b_lds = (size_t)b_off + (size_t)N1 * 8 <= SEL_BUF_BYTES;
+    uint64_t* s_B = (uint64_t*)(s_buf + b_off);
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
     if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, s_n, fin, fin_cnt_out, flags);
@@ -422,7 +425,12 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
     const Plan& P = c->plan;
     for (int L = 0; L < P.nlevels; L++)
         if (P.lv[L].nstrips > SEL_MAXSTRIPS) return mo_fail(c, MO_ERR_UNSUPPORTED, "too many strips per level");
-    hipLaunchKernelGGL(k_select, dim3(P.nlevels, batch), dim3(64), 0, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BUF_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_select, dim3(P.nlevels, batch), dim3(64), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
                        c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags);
     HIPCHK(c, hipGetLastError());
     return MO_OK;

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     double* xn = w.xn + (size_t)pair * a.cap * 4;
     float* px = w.px + (size_t)pair * a.cap * 4;
     int* qidx = w.qidx + (size_t)pair * a.cap;
-    if (tid == 0) { s_base = 0; w.best[pair] = 0ull; }
+    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; }
     __syncthreads();
     if (a.d_p1) {  // explicit correspondences
         int m = a.m_fixed;
@@ -301,7 +301,9 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
         double* o = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
         for (int j = 0; j < 9; j++) o[j] = E[j];
     }
-    int count = 0;
+    // MSAC score: sum of Sampson distances truncated at thr^2 (a pure inlier count prefers slightly perturbed
+    // models that catch more chance inliers).  Compared as float32, ties -> lowest hypothesis index.
+    double cost = 0.0;
     for (int base = 0; base < m; base += TV_CHUNK) {
         int n = min(TV_CHUNK, m - base);
         __syncthreads();
@@ -310,20 +312,21 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
         if (valid) {
             for (int i = 0; i < n; i++) {
                 double err = sampson(E, s_pts[4 * i], s_pts[4 * i + 1], s_pts[4 * i + 2], s_pts[4 * i + 3]);
-                count += err <= thr2 ? 1 : 0;
+                cost += fmin(err, thr2);
             }
         }
     }
-    unsigned long long key = valid ? (((unsigned long long)count << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h)) : 0ull;
+    unsigned long long key = ~0ull;
+    if (valid && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long other = __shfl_xor(key, o, 64);
-        key = other > key ? other : key;
+        key = other < key ? other : key;
     }
     if ((tid & 63) == 0) s_best[tid >> 6] = key;
     __syncthreads();
     if (tid == 0) {
-        for (int k = 1; k < TV_BLOCK / 64; k++) key = s_best[k] > key ? s_best[k] : key;
-        if (key) atomicMax(&w.best[pair], key);
+        for (int k = 1; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;
+        if (key != ~0ull) atomicMin(&w.best[pair], key);
     }
 }
 
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         if (ran_out) ran_out[i] = 0;
     }
     const unsigned long long best = w.best[pair];
-    if (m < 8 || best == 0ull) {
+    if (m < 8 || best == ~0ull) {
         if (tid == 0) {
             a.d_n_points[pair] = 0;
             if (pose) for (int j = 0; j < 12; j++) pose[j] = __longlong_as_double(0x7FF8000000000000ll);
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         }
         return;
     }
-    const int hbest = (int)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+    const int hbest = (int)(unsigned)(best & 0xFFFFFFFFull);
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
     const float* px = w.px + (size_t)pair * a.cap * 4;
     const int* qidx = w.qidx + (size_t)pair * a.cap;
@@ -404,42 +407,87 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     if (tid < 9) s_E[tid] = w.hypE[((size_t)pair * a.n_hyp + hbest) * 9 + tid];
     __syncthreads();
 
-    // ---- least-squares refit on the consensus set: accumulate the 9x9 normal matrix (45 unique sums)
-    double acc[45];
-    for (int j = 0; j < 45; j++) acc[j] = 0;
+    // ---- local optimisation: least-squares 8-point refits (9x9 normal matrix, 45 unique sums, Jacobi) on an
+    // adaptively tightened consensus set.  The selection threshold follows a 3-sigma rule on the mean Sampson
+    // residual of the previous selection, clamped to [thr/64, thr], so chance inliers of the loose RANSAC threshold
+    // do not bias the algebraic fit; a refit is only accepted while >= half of the original consensus is selected.
+    __shared__ double s_N[45];
+    __shared__ int s_stop;
+    const double lo2 = thr2 / 4096.0;
+    int n0;
+    double tau2;
     {
         double E[9];
         for (int j = 0; j < 9; j++) E[j] = s_E[j];
+        int cnt = 0;
+        double sd = 0;
         for (int i = tid; i < m; i += TV_BLOCK) {
-            double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
-            if (sampson(E, x1, y1, x2, y2) <= thr2) {
-                double r[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
-                int k = 0;
+            double d = sampson(E, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]);
+            if (d <= thr2) { cnt++; sd += d; }
+        }
+        n0 = block_sum_i(cnt, s_redi);
+        double sds = block_sum(sd, s_red);
+        tau2 = n0 > 0 ? fmin(fmax(9.0 * sds / n0, lo2), thr2) : thr2;
+    }
+    if (n0 < 8) {  // block-uniform: the best model does not even explain a minimal sample
+        if (tid == 0) {
+            a.d_n_points[pair] = 0;
+            if (pose) for (int j = 0; j < 12; j++) pose[j] = __longlong_as_double(0x7FF8000000000000ll);
+            if (a.d_E) for (int j = 0; j < 9; j++) a.d_E[(size_t)pair * 9 + j] = __longlong_as_double(0x7FF8000000000000ll);
+        }
+        return;
+    }
+    for (int it = 0; it < 5; it++) {
+        double acc[45];
+        for (int j = 0; j < 45; j++) acc[j] = 0;
+        int cnt = 0;
+        double sd = 0;
+        {
+            double E[9];
+            for (int j = 0; j < 9; j++) E[j] = s_E[j];
+            for (int i = tid; i < m; i += TV_BLOCK) {
+                double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
+                double d = sampson(E, x1, y1, x2, y2);
+                if (d <= tau2) {
+                    double r[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+                    int k = 0;
 #pragma unroll
-                for (int p = 0; p < 9; p++)
+                    for (int p = 0; p < 9; p++)
 #pragma unroll
-                    for (int q = p; q < 9; q++) acc[k++] += r[p] * r[q];
+                        for (int q = p; q < 9; q++) acc[k++] += r[p] * r[q];
+                    cnt++;
+                    sd += d;
+                }
             }
         }
-    }
-    __shared__ double s_N[45];
-    for (int j = 0; j < 45; j++) {
-        double v = block_sum(acc[j], s_red);
-        if (tid == 0) s_N[j] = v;
+        const int c = block_sum_i(cnt, s_redi);
+        if (c < 8 || 2 * c < n0) break;  // block-uniform
+        const double sds = block_sum(sd, s_red);
+        for (int j = 0; j < 45; j++) {
+            double v = block_sum(acc[j], s_red);
+            if (tid == 0) s_N[j] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double A[81], V[81];
+            int k = 0;
+            for (int p = 0; p < 9; p++)
+                for (int q = p; q < 9; q++) { A[p * 9 + q] = s_N[k]; A[q * 9 + p] = s_N[k]; k++; }
+            jacobi_eig<9>(A, V);
+            int mn = 0;
+            for (int i = 1; i < 9; i++) if (A[i * 9 + i] < A[mn * 9 + mn]) mn = i;
+            double E[9];
+            for (int i = 0; i < 9; i++) E[i] = V[i * 9 + mn];
+            bool ok = project_essential(E);
+            if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
+            s_stop = ok ? 0 : 1;
+        }
+        __syncthreads();
+        if (s_stop) break;
+        tau2 = fmin(fmax(9.0 * sds / c, lo2), thr2);
     }
     __syncthreads();
     if (tid == 0) {
-        double A[81], V[81];
-        int k = 0;
-        for (int p = 0; p < 9; p++)
-            for (int q = p; q < 9; q++) { A[p * 9 + q] = s_N[k]; A[q * 9 + p] = s_N[k]; k++; }
-        jacobi_eig<9>(A, V);
-        int mn = 0;
-        for (int i = 1; i < 9; i++) if (A[i * 9 + i] < A[mn * 9 + mn]) mn = i;
-        double E[9];
-        for (int i = 0; i < 9; i++) E[i] = V[i * 9 + mn];
-        bool ok = project_essential(E);
-        if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the best hypothesis
         // decompose: R1 = U W V^T, R2 = U W^T V^T, t = u3
         double U[9], Vm[9], sg[3], Ef[9];
         for (int i = 0; i < 9; i++) Ef[i] = s_E[i];
