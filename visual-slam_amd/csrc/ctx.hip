@@ -263,7 +263,8 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         v.fin_cap = std::max(1, std::min(v.cand_cap, 4 * v.quota + 256));
         fin_off += v.fin_cap;
         v.scr_off = scr_off;
-        scr_off += (v.cand_cap * 3 + 1) / 2 + 2;  // u32 array A + u64 array B, in u64 units
+        // u64 records B + u32 records A + u16 partner positions + u64 ballots, in u64 units
+        scr_off += v.cand_cap + (v.cand_cap + 1) / 2 + (v.cand_cap / 2 + 8) / 4 + 2 + v.cand_cap / 64 + 4;
     }
     P.pyr_stride = std::max(pyr_off, 256);
     P.blur_stride = blur_off;

@@ -336,10 +336,16 @@ __device__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) 
     return ((t1 - t2) - t4) * scale_sq_sq;
 }
 
+// Record window layout (LDS, SEL_BUF_BYTES): [records | rpos u16 x n/2 | ballots u64 x (n/64 + 1)]; the same layout is
+// used inside the level's HBM scratch slot when a level has more candidates than the window holds.
+__device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
+    return (((size_t)n * rec_bytes + 7) & ~(size_t)7) + ((((size_t)n / 2 + 1) * 2 + 7) & ~(size_t)7) + ((size_t)n / 64 + 2) * 8;
+}
+
 // phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota), write-out
 template <class PA, class PB>
-__device__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1, int* s_n,
-                              FinalKp* fin, int* fin_cnt_out, int* flags) {
+__device__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1, uint16_t* rpos,
+                              unsigned long long* bl, FinalKp* fin, int* fin_cnt_out, int* flags) {
     const int lane = threadIdx.x;
     for (int i = lane; i < N1; i += WAVE) {
         uint32_t e = A[i];
@@ -348,9 +354,7 @@ __device__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t*
         B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
     }
     __syncthreads();
-    if (lane == 0) s_n[1] = replay::retain_best<uint64_t>(B, N1, lv.quota, P.select_order);
-    __syncthreads();
-    int N2 = s_n[1];
+    int N2 = replay::wave_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, lane);
     if (N2 > lv.fin_cap) {
         if (lane == 0) atomicOr(&flags[0], 1);
         N2 = lv.fin_cap;
@@ -372,8 +376,6 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
                                                FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // SEL_BUF_BYTES
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
-    __shared__ int s_n[2];
-    uint32_t* s_A = (uint32_t*)s_buf;
     const int L = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
@@ -390,10 +392,16 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
     }
     __syncthreads();
     const int N = s_pref[lv.nstrips];
+    // HBM scratch slot of this (frame, level): [B records u64 x cap | A records u32 x cap | rpos | ballots]
     uint64_t* scr = scratch + (size_t)frame * scratch_stride + lv.scr_off;
-    uint64_t* gB = scr;                                  // cand_cap u64
-    uint32_t* gA = (uint32_t*)(scr + lv.cand_cap);       // cand_cap u32
-    const bool a_lds = N <= SEL_ACAP;
+    uint64_t* gB = scr;
+    uint32_t* gA = (uint32_t*)(scr + lv.cand_cap);
+    uint16_t* g_rpos = (uint16_t*)(gA + lv.cand_cap + (lv.cand_cap & 1));
+    unsigned long long* g_bl = (unsigned long long*)(g_rpos + (((size_t)lv.cand_cap / 2 + 4) & ~(size_t)3));
+    const bool a_lds = sel_need_bytes(N, 4) <= SEL_BUF_BYTES;
+    uint32_t* s_A = (uint32_t*)s_buf;
+    uint16_t* a_rpos = (uint16_t*)(s_buf + (((size_t)N * 4 + 7) & ~(size_t)7));
+    unsigned long long* a_bl = (unsigned long long*)((uint8_t*)a_rpos + ((((size_t)N / 2 + 1) * 2 + 7) & ~(size_t)7));
     const uint32_t* src = cand + (size_t)frame * P.cand_stride + lv.cand_off;
     for (int s = 0; s < lv.nstrips; s++) {
         int b = s_pref[s], n = s_pref[s + 1] - b;
@@ -402,23 +410,23 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
         else for (int i = lane; i < n; i += WAVE) gA[b + i] = e[i];
     }
     __syncthreads();
-    // pass 1: retainBest(2 * quota) on the FAST score, one lane replays the library permutation
-    if (lane == 0) {
-        if (a_lds) s_n[0] = replay::retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order);
-        else s_n[0] = replay::retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order);
-    }
+    // pass 1: retainBest(2 * quota) on the FAST score
+    int N1;
+    if (a_lds) N1 = replay::wave_retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, lane);
+    else N1 = replay::wave_retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, lane);
     __syncthreads();
-    const int N1 = s_n[0];
-    // the Harris records go behind the surviving FAST records when both fit the window
-    const int b_off = a_lds ? ((N1 * 4 + 7) & ~7) : 0;
-    const bool b_lds = (size_t)b_off + (size_t)N1 * 8 <= SEL_BUF_BYTES;
+    // the Harris records (and their rpos / ballots) go behind the surviving FAST records when both fit the window
+    const size_t b_off = a_lds ? (((size_t)N1 * 4 + 15) & ~(size_t)15) : 0;
+    const bool b_lds = b_off + sel_need_bytes(N1, 8) <= SEL_BUF_BYTES;
     uint64_t* s_B = (uint64_t*)(s_buf + b_off);
+    uint16_t* b_rpos = (uint16_t*)((uint8_t*)s_B + (size_t)N1 * 8);
+    unsigned long long* b_bl = (unsigned long long*)((uint8_t*)b_rpos + ((((size_t)N1 / 2 + 1) * 2 + 7) & ~(size_t)7));
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
-    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, s_n, fin, fin_cnt_out, flags);
-    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, s_n, fin, fin_cnt_out, flags);
-    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, s_n, fin, fin_cnt_out, flags);
-    else select_harris(P, lv, img, gA, gB, N1, s_n, fin, fin_cnt_out, flags);
+    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags);
+    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags);
+    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags);
+    else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags);
 }
 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
@@ -436,23 +444,25 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
     return MO_OK;
 }
 
-// probe for the parity tests: retainBest on a bare float response array (u64 record path)
-__global__ void k_retain_probe(const float* resp, int n, int n_points, int order, uint64_t* rec, int32_t* out, int* nout) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) rec[i] = ((uint64_t)__float_as_uint(resp[i]) << 32) | (uint32_t)i;
+// probe for the parity tests: retainBest on a bare float response array (u64 record path, HBM-resident records)
+__global__ __launch_bounds__(64) void k_retain_probe(const float* resp, int n, int n_points, int order, uint64_t* rec,
+                                                     uint16_t* rpos, unsigned long long* bl, int32_t* out, int* nout) {
+    for (int i = threadIdx.x; i < n; i += 64) rec[i] = ((uint64_t)__float_as_uint(resp[i]) << 32) | (uint32_t)i;
     __syncthreads();
-    __shared__ int s_n;
-    if (threadIdx.x == 0) s_n = replay::retain_best<uint64_t>(rec, n, n_points, order);
+    int keep = replay::wave_retain_best<uint64_t>(rec, n, n_points, order, rpos, bl, threadIdx.x);
     __syncthreads();
-    for (int i = threadIdx.x; i < s_n; i += blockDim.x) out[i] = (int32_t)(rec[i] & 0xFFFFFFFFu);
-    if (threadIdx.x == 0) *nout = s_n;
+    for (int i = threadIdx.x; i < keep; i += 64) out[i] = (int32_t)(rec[i] & 0xFFFFFFFFu);
+    if (threadIdx.x == 0) *nout = keep;
 }
 
 int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order, int* d_nout) {
-    size_t need = (size_t)std::max(n, 1) * sizeof(uint64_t);
-    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, need);
+    size_t nn = (size_t)std::max(n, 1);
+    size_t rec_b = nn * sizeof(uint64_t), rpos_b = ((nn / 2 + 4) * 2 + 7) & ~(size_t)7, bl_b = (nn / 64 + 2) * 8;
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, rec_b + rpos_b + bl_b);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_retain_probe, dim3(1), dim3(64), 0, c->stream, d_resp, n, n_points, order, (uint64_t*)c->d_tmp,
-                       d_order, d_nout);
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    hipLaunchKernelGGL(k_retain_probe, dim3(1), dim3(64), 0, c->stream, d_resp, n, n_points, order, (uint64_t*)b,
+                       (uint16_t*)(b + rec_b), (unsigned long long*)(b + rec_b + rpos_b), d_order, d_nout);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

@@ -133,9 +133,7 @@ template <class T, class P> __device__ void ls_insertion_sort(P a, int first, in
     }
 }
 
-template <class T, class P> __device__ void ls_nth_element(P a, int first, int nth, int last) {
-    if (first == last || nth == last) return;
-    int depth = (31 - __clz(last - first)) * 2;
+template <class T, class P> __device__ void ls_introselect(P a, int first, int nth, int last, int depth) {
     while (last - first > 3) {
         if (depth == 0) {
             ls_heap_select<T>(a, first, nth + 1, last);
@@ -150,6 +148,11 @@ template <class T, class P> __device__ void ls_nth_element(P a, int first, int n
         else last = cut;
     }
     ls_insertion_sort<T>(a, first, last);
+}
+
+template <class T, class P> __device__ void ls_nth_element(P a, int first, int nth, int last) {
+    if (first == last || nth == last) return;
+    ls_introselect<T>(a, first, nth, last, (31 - __clz(last - first)) * 2);
 }
 
 // ---------------------------------------------------------------- MSVC STL -------------------------
@@ -278,6 +281,128 @@ template <class T, class P> __device__ int retain_best(P a, int n, int n_points,
     else ls_nth_element<T>(a, 0, n_points - 1, n);
     T amb = a[n_points - 1];
     return n_points + partition_ge<T>(a, n_points, n, amb);
+}
+
+
+// ================================================================ wave-parallel replay (libstdc++ order) ============
+// The Hoare partition of libstdc++'s introselect is a pairing: the k-th element from the left that stops the
+// upward scan (not better than the pivot) is swapped with the k-th element from the right that stops the downward
+// scan (not worse than the pivot), for as long as the left one lies before the right one.  Ranks are prefix counts,
+// so one wavefront computes the whole partition in three passes of ballots + popcounts instead of a serial walk,
+// and reproduces the serial permutation exactly:
+//   L_k = k-th position from the left with !(a > pivot),  R_k = k-th from the right with !(pivot > a)
+//   K   = #{k : L_k < R_k};  swap a[L_k] <-> a[R_k] for k <= K;  cut = min(L_{K+1}, R_K)
+// All 64 lanes call these functions convergently (block = one wavefront).  rpos: u16[>= n/2], bl: u64[>= n/64 + 1].
+#define REPLAY_SERIAL_BELOW 160  // ranges this short are finished by one lane (three wave passes cost more)
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// generic pairing partition: stopL(v) / stopR(v) classify an element; returns cut (absolute index) and total of R
+template <class T, class P, class FL, class FR>
+__device__ int wave_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
+                                   int lane, int* total_r) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int TR = 0;
+    for (int c0 = lo, ch = 0; c0 < hi; c0 += 64, ch++) {
+        int i = c0 + lane;
+        bool in = i < hi;
+        T v = a[in ? i : lo];
+        unsigned long long mL = __ballot(in && stopL(v)), mR = __ballot(in && stopR(v));
+        if (lane == 0) bl[ch] = mL;
+        TR += __popcll(mR);
+    }
+    int baseL = 0, baseR = 0, K = 0, minNL = 0x7FFFFFFF, minSR = 0x7FFFFFFF;
+    for (int c0 = lo; c0 < hi; c0 += 64) {
+        int i = c0 + lane;
+        bool in = i < hi;
+        T v = a[in ? i : lo];
+        bool isL = in && stopL(v), isR = in && stopR(v);
+        unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+        int cL = baseL + __popcll(mL & lt), cR = baseR + __popcll(mR & lt);
+        int kL = cL + 1, kR = TR - cR;
+        bool swL = isL && (TR - cR - (isR ? 1 : 0)) >= kL;   // R_kL lies strictly right of this element
+        bool swR = isR && cL >= kR;                          // L_kR lies strictly left of this element
+        if (swR) rpos[kR - 1] = (uint16_t)(i - lo);
+        if (isL && !swL) minNL = min(minNL, i);
+        if (swR) minSR = min(minSR, i);
+        K += __popcll(__ballot(swL));
+        baseL += __popcll(mL);
+        baseR += __popcll(mR);
+    }
+    __syncthreads();
+    baseL = 0;
+    for (int c0 = lo, ch = 0; c0 < hi && baseL < K; c0 += 64, ch++) {
+        unsigned long long mL = bl[ch];
+        int kL = baseL + __popcll(mL & lt) + 1;
+        if (((mL >> lane) & 1ull) && kL <= K) {
+            int p = c0 + lane, q = lo + rpos[kL - 1];
+            T vp = a[p], vq = a[q];
+            a[p] = vq;
+            a[q] = vp;
+        }
+        baseL += __popcll(mL);
+    }
+    __syncthreads();
+    if (total_r) *total_r = TR;
+    return min(wave_min_i(minNL), wave_min_i(minSR));
+}
+
+template <class T, class P>
+__device__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int lane) {
+    typedef Rec<T> R;
+    if (first == last || nth == last) return;
+    int depth = (31 - __clz(last - first)) * 2;
+    while (last - first > 3) {
+        if (last - first < REPLAY_SERIAL_BELOW || last - first > 65535 || depth == 0) {
+            if (lane == 0) ls_introselect<T>(a, first, nth, last, depth);  // identical continuation, one lane
+            __syncthreads();
+            return;
+        }
+        --depth;
+        int mid = first + (last - first) / 2;
+        if (lane == 0) ls_move_median_to_first<T>(a, first, first + 1, mid, last - 1);
+        __syncthreads();
+        const T pv = a[first];
+        int cut = wave_pair_partition<T>(
+            a, first + 1, last, [pv](T v) { return !R::gt(v, pv); }, [pv](T v) { return !R::gt(pv, v); }, rpos, bl, lane,
+            (int*)nullptr);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (lane == 0) ls_insertion_sort<T>(a, first, last);
+    __syncthreads();
+}
+
+// retainBest, all lanes convergent.  libstdc++ order runs wave-parallel; the MSVC STL's three-way partition is
+// replayed by one lane.
+template <class T, class P>
+__device__ int wave_retain_best(P a, int n, int n_points, int order, uint16_t* rpos, unsigned long long* bl, int lane) {
+    typedef Rec<T> R;
+    if (n_points < 0 || n <= n_points) return n;
+    if (n_points == 0) return 0;
+    if (order == MO_ORDER_MSVC) {
+        if (lane == 0) ms_nth_element<T>(a, 0, n_points - 1, n);
+        __syncthreads();
+    } else {
+        wave_ls_nth_element<T>(a, 0, n_points - 1, n, rpos, bl, lane);
+    }
+    const T amb = a[n_points - 1];
+    int tail = n - n_points;
+    if (tail < REPLAY_SERIAL_BELOW || tail > 65535) {
+        __shared__ int s_keep;
+        if (lane == 0) s_keep = partition_ge<T>(a, n_points, n, amb);
+        __syncthreads();
+        return n_points + s_keep;
+    }
+    int total_true = 0;
+    wave_pair_partition<T>(
+        a, n_points, n, [amb](T v) { return !R::ge(v, amb); }, [amb](T v) { return R::ge(v, amb); }, rpos, bl, lane,
+        &total_true);
+    return n_points + total_true;
 }
 
 }  // namespace replay

@@ -51,38 +51,81 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
 // ---------------------------------------------------------------- small dense helpers -------------
 // cyclic Jacobi eigen-decomposition of a symmetric NxN matrix (row-major a, eigenvectors in columns of v)
 template <int N> __device__ void jacobi_eig(double* a, double* v) {
+#pragma unroll
     for (int i = 0; i < N; i++)
+#pragma unroll
         for (int j = 0; j < N; j++) v[i * N + j] = i == j ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0, diag = 0;
+#pragma unroll
         for (int i = 0; i < N; i++)
+#pragma unroll
             for (int j = 0; j < N; j++) {
                 if (i != j) off += a[i * N + j] * a[i * N + j];
                 else diag += a[i * N + j] * a[i * N + j];
             }
         if (off <= 1e-30 * diag || off == 0.0) break;
+#pragma unroll
         for (int p = 0; p < N - 1; p++)
+#pragma unroll
             for (int q = p + 1; q < N; q++) {
                 double apq = a[p * N + q];
-                if (apq == 0.0) continue;
-                double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
+                if (apq != 0.0) {
+                    double theta = (a[q * N + q] - a[p * N + p]) / (2.0 * apq);
+                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double akp = a[k * N + p], akq = a[k * N + q];
+                        a[k * N + p] = c * akp - s * akq;
+                        a[k * N + q] = s * akp + c * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double apk = a[p * N + k], aqk = a[q * N + k];
+                        a[p * N + k] = c * apk - s * aqk;
+                        a[q * N + k] = s * apk + c * aqk;
+                    }
+#pragma unroll
+                    for (int k = 0; k < N; k++) {
+                        double vkp = v[k * N + p], vkq = v[k * N + q];
+                        v[k * N + p] = c * vkp - s * vkq;
+                        v[k * N + q] = s * vkp + c * vkq;
+                    }
+                }
+            }
+    }
+}
+
+// 9x9 symmetric eigen-decomposition by cyclic Jacobi with the matrix in LDS and one lane per row/column
+// (lanes 0..8 of one wavefront; every lane of that wavefront must call).  a, v: volatile LDS [81].
+__device__ void jacobi9_lanes(volatile double* a, volatile double* v, int lane) {
+    const int k = lane < 9 ? lane : 0;
+    if (lane < 9)
+        for (int j = 0; j < 9; j++) v[lane * 9 + j] = lane == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, diag = 0;
+        if (lane < 9)
+            for (int j = 0; j < 9; j++) {
+                double x = a[lane * 9 + j];
+                if (j != lane) off += x * x; else diag += x * x;
+            }
+        for (int o = 8; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); diag += __shfl_xor(diag, o, 64); }
+        off = __shfl(off, 0, 64); diag = __shfl(diag, 0, 64);
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < 8; p++)
+            for (int q = p + 1; q < 9; q++) {
+                double apq = a[p * 9 + q];
+                if (apq == 0.0) continue;  // wave-uniform
+                double theta = (a[q * 9 + q] - a[p * 9 + p]) / (2.0 * apq);
                 double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < N; k++) {
-                    double akp = a[k * N + p], akq = a[k * N + q];
-                    a[k * N + p] = c * akp - s * akq;
-                    a[k * N + q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < N; k++) {
-                    double apk = a[p * N + k], aqk = a[q * N + k];
-                    a[p * N + k] = c * apk - s * aqk;
-                    a[q * N + k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < N; k++) {
-                    double vkp = v[k * N + p], vkq = v[k * N + q];
-                    v[k * N + p] = c * vkp - s * vkq;
-                    v[k * N + q] = s * vkp + c * vkq;
-                }
+                double akp = a[k * 9 + p], akq = a[k * 9 + q];
+                if (lane < 9) { a[k * 9 + p] = c * akp - s * akq; a[k * 9 + q] = s * akp + c * akq; }
+                double apk = a[p * 9 + k], aqk = a[q * 9 + k];
+                if (lane < 9) { a[p * 9 + k] = c * apk - s * aqk; a[q * 9 + k] = s * apk + c * aqk; }
+                double vkp = v[k * 9 + p], vkq = v[k * 9 + q];
+                if (lane < 9) { v[k * 9 + p] = c * vkp - s * vkq; v[k * 9 + q] = s * vkp + c * vkq; }
             }
     }
 }
@@ -412,6 +455,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     // residual of the previous selection, clamped to [thr/64, thr], so chance inliers of the loose RANSAC threshold
     // do not bias the algebraic fit; a refit is only accepted while >= half of the original consensus is selected.
     __shared__ double s_N[45];
+    __shared__ double s_part[TV_BLOCK / 64][45];
+    __shared__ volatile double s_A9[81], s_V9[81];
     __shared__ int s_stop;
     const double lo2 = thr2 / 4096.0;
     int n0;
@@ -463,24 +508,31 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         const int c = block_sum_i(cnt, s_redi);
         if (c < 8 || 2 * c < n0) break;  // block-uniform
         const double sds = block_sum(sd, s_red);
+        // 45 sums: wave shuffle reduction, per-wave partials in LDS, one barrier
         for (int j = 0; j < 45; j++) {
-            double v = block_sum(acc[j], s_red);
-            if (tid == 0) s_N[j] = v;
+            double v = acc[j];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((tid & 63) == 0) s_part[tid >> 6][j] = v;
         }
         __syncthreads();
-        if (tid == 0) {
-            double A[81], V[81];
-            int k = 0;
-            for (int p = 0; p < 9; p++)
-                for (int q = p; q < 9; q++) { A[p * 9 + q] = s_N[k]; A[q * 9 + p] = s_N[k]; k++; }
-            jacobi_eig<9>(A, V);
-            int mn = 0;
-            for (int i = 1; i < 9; i++) if (A[i * 9 + i] < A[mn * 9 + mn]) mn = i;
-            double E[9];
-            for (int i = 0; i < 9; i++) E[i] = V[i * 9 + mn];
-            bool ok = project_essential(E);
-            if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
-            s_stop = ok ? 0 : 1;
+        if (tid < 45) s_N[tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+        __syncthreads();
+        if (tid < 64) {  // wave 0: expand the symmetric matrix and diagonalise it with one lane per column
+            if (tid == 0) {
+                int k = 0;
+                for (int p = 0; p < 9; p++)
+                    for (int q = p; q < 9; q++) { s_A9[p * 9 + q] = s_N[k]; s_A9[q * 9 + p] = s_N[k]; k++; }
+            }
+            jacobi9_lanes(s_A9, s_V9, tid);
+            if (tid == 0) {
+                int mn = 0;
+                for (int i = 1; i < 9; i++) if (s_A9[i * 9 + i] < s_A9[mn * 9 + mn]) mn = i;
+                double E[9];
+                for (int i = 0; i < 9; i++) E[i] = s_V9[i * 9 + mn];
+                bool ok = project_essential(E);
+                if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
+                s_stop = ok ? 0 : 1;
+            }
         }
         __syncthreads();
         if (s_stop) break;
