@@ -43,21 +43,43 @@ STAGE_BYTES = {
 }
 
 
+def _scene(seed, w, h, rects_per_vga):
+    """Seeded canvas: smooth low-contrast shading + many small uniform-grey rectangles (strong, repeatable corners)
+    + N(0,1) texture noise baked in."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    cw, ch = w // 32 + 2, h // 32 + 2
+    cells = rng.uniform(90, 170, size=(ch, cw))
+    ys = (np.arange(h) + 0.5) / 32.0
+    xs = (np.arange(w) + 0.5) / 32.0
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    img = (cells[y0][:, x0] * (1 - fy) * (1 - fx) + cells[y0][:, x0 + 1] * (1 - fy) * fx +
+           cells[y0 + 1][:, x0] * fy * (1 - fx) + cells[y0 + 1][:, x0 + 1] * fy * fx)
+    for _ in range(rects_per_vga * w // W):
+        rw, rh = rng.integers(5, 22, size=2)
+        x = rng.integers(0, w - 1); y = rng.integers(0, h - 1)
+        img[y:y + rh, x:x + rw] = rng.uniform(0, 255)
+    img = img + rng.normal(0, 1.0, size=img.shape)
+    return np.clip(img, 0, 255).astype(np.float32)
+
+
 def make_frames(torch, device, first, count, seed=20250523):
-    """Frames [first, first+count) of the global synthetic sequence: a sliding 640x480 window over a seeded
-    textured canvas (2 px / frame pan with a slow vertical drift) plus per-frame N(0,2) noise."""
-    from tests.helpers import synthetic_frame
-    span = 1024
-    canvas = np.concatenate([synthetic_frame(seed + k, W, H + 64) for k in range((span + W) // W + 2)], axis=1)
-    cv = torch.from_numpy(canvas).to(device=device, dtype=torch.float32)
+    """Frames [first, first+count) of the global synthetic sequence: a camera translating along x past a two-depth
+    scene (background pans 8 px / frame, foreground patches 16 px / frame, i.e. depths 40 and 20 baselines at
+    f = 320) plus per-frame N(0,1) sensor noise.  Non-planar, ~850 ratio-test matches per consecutive pair."""
+    span = 2048
+    wide = span + 2 * W
+    bg = torch.from_numpy(_scene(seed, wide, H, 800)).to(device)
+    fg = torch.from_numpy(_scene(seed + 1, wide, H, 800)).to(device)
+    mk = torch.from_numpy(_scene(seed + 2, wide, H, 40)).to(device)
     out = torch.empty((count, H, W), dtype=torch.uint8, device=device)
     for i in range(count):
         g = first + i
-        x0 = (2 * g) % span
-        y0 = 16 + int(round(12 * np.sin(g / 40.0)))
+        xb, xf = (8 * g) % span, (16 * g) % span
         gen = torch.Generator(device=device)
         gen.manual_seed(seed * 1000003 + g)
-        fr = cv[y0:y0 + H, x0:x0 + W] + 2.0 * torch.randn((H, W), generator=gen, device=device)
+        fr = torch.where(mk[:, xf:xf + W] > 130.0, fg[:, xf:xf + W], bg[:, xb:xb + W])
+        fr = fr + 1.0 * torch.randn((H, W), generator=gen, device=device)
         out[i] = fr.round().clamp_(0, 255).to(torch.uint8)
     return out
 
@@ -193,7 +215,8 @@ def main():
                                    "+ BF-Hamming 2-NN ratio 0.75 on consecutive pairs + 8-pt E RANSAC (%d hyp) pose/DLT per pair"
                                    % (B, N_HYP),
                        "frames_per_gpu": B, "n_features": NFEAT, "hypotheses": N_HYP,
-                       "keypoints_per_frame_mean": float(cnt.mean()), "map_points_per_pair_mean": float(npt.mean()),
+                       "keypoints_per_frame_mean": float(cnt.mean()), "matches_per_pair_mean": float(mpass.sum(dim=1).float().mean().item()),
+                       "map_points_per_pair_mean": float(npt.mean()),
                        "parallelism": "frame-sharded x%d, RCCL gather of map points" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,

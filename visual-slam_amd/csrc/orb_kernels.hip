@@ -93,43 +93,88 @@ struct TileTab {
 
 #define BT_W 64
 #define BT_H 16
+#define BT_PW 80  // LDS pixel-tile pitch: 4 (aligned lead-in) + 64 + 3 halo, rounded to a multiple of 16
 
+// 7x7 Gaussian (8-bit quantised taps, sum 257), separable through LDS: u8 tile -> u16 row sums -> u8 output.
+// Interior tiles are staged with aligned dword loads; tiles touching the level border index with REFLECT_101.
 __global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* __restrict__ gray,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    __shared__ uint8_t s_px[(BT_H + 6) * (BT_W + 8)];
-    __shared__ uint16_t s_row[(BT_H + 6) * BT_W];
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[(BT_H + 6) * BT_PW];
+    __shared__ __attribute__((aligned(16))) uint16_t s_row[(BT_H + 6) * BT_W];
     int tile = blockIdx.x, frame = blockIdx.y;
     int L = 0;
     while (L + 1 < T.nlevels && tile >= T.cum[L + 1]) L++;
     tile -= T.cum[L];
     const LevelInfo lv = P.lv[L];
-    int tx0 = (tile % T.tx[L]) * BT_W, ty0 = (tile / T.tx[L]) * BT_H;
+    const int tx0 = (tile % T.tx[L]) * BT_W, ty0 = (tile / T.tx[L]) * BT_H;
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
-    const int PW = BT_W + 8;
-    for (int i = threadIdx.x; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        int r = i / (BT_W + 6), cidx = i - r * (BT_W + 6);
-        int y = reflect101(ty0 + r - 3, lv.h), x = reflect101(tx0 + cidx - 3, lv.w);
-        s_px[r * PW + cidx] = img[(size_t)y * lv.pitch + x];
+    const int tid = threadIdx.x;
+    // s_px column c holds level column tx0 - 4 + c  (c = 1 .. 70 are used)
+    const bool interior = tx0 >= 4 && ty0 >= 3 && tx0 + BT_W + 4 <= lv.w && ty0 + BT_H + 3 <= lv.h &&
+                          (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
+    if (interior) {
+        for (int i = tid; i < (BT_H + 6) * 18; i += 256) {
+            int r = i / 18, c4 = i - r * 18;
+            const uint32_t* src = (const uint32_t*)(img + (size_t)(ty0 + r - 3) * lv.pitch + tx0 - 4);
+            ((uint32_t*)(s_px + r * BT_PW))[c4] = src[c4];
+        }
+    } else {
+        for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+            int r = i / (BT_W + 6), cidx = i - r * (BT_W + 6);
+            int y = reflect101(ty0 + r - 3, lv.h), x = reflect101(tx0 + cidx - 3, lv.w);
+            s_px[r * BT_PW + cidx + 1] = img[(size_t)y * lv.pitch + x];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (BT_H + 6) * BT_W; i += 256) {
-        int r = i / BT_W, cidx = i % BT_W;
-        const uint8_t* p = &s_px[r * PW + cidx];
-        int acc = P.gk[0] * p[0] + P.gk[1] * p[1] + P.gk[2] * p[2] + P.gk[3] * p[3] + P.gk[4] * p[4] +
-                  P.gk[5] * p[5] + P.gk[6] * p[6];
-        s_row[i] = (uint16_t)acc;  // <= 257 * 255 = 65535
+    const int g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];
+    // row pass: one task = 4 adjacent outputs of one tile row, fed by three aligned dword reads (12 pixels)
+    for (int task = tid; task < (BT_H + 6) * 16; task += 256) {
+        const int r = task >> 4, q = task & 15;
+        const uint32_t* pw = (const uint32_t*)(s_px + r * BT_PW + 4 * q);
+        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+        int px[12];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            px[k] = (w0 >> (8 * k)) & 0xFF;
+            px[4 + k] = (w1 >> (8 * k)) & 0xFF;
+            px[8 + k] = (w2 >> (8 * k)) & 0xFF;
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // output column 4q+k is centred on s_px column 4q+k+4
+            const int* p = &px[k + 1];
+            o[k] = (uint32_t)(g0 * (p[0] + p[6]) + g1 * (p[1] + p[5]) + g2 * (p[2] + p[4]) + g3 * p[3]);  // <= 65535
+        }
+        uint2 packed;
+        packed.x = o[0] | (o[1] << 16);
+        packed.y = o[2] | (o[3] << 16);
+        *(uint2*)(&s_row[r * BT_W + 4 * q]) = packed;
     }
     __syncthreads();
-    uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff;
-    for (int i = threadIdx.x; i < BT_H * BT_W; i += 256) {
-        int r = i / BT_W, cidx = i % BT_W;
-        int x = tx0 + cidx, y = ty0 + r;
-        if (x >= lv.w || y >= lv.h) continue;
-        const uint16_t* p = &s_row[r * BT_W + cidx];
-        int acc = P.gk[0] * p[0] + P.gk[1] * p[BT_W] + P.gk[2] * p[2 * BT_W] + P.gk[3] * p[3 * BT_W] +
-                  P.gk[4] * p[4 * BT_W] + P.gk[5] * p[5 * BT_W] + P.gk[6] * p[6 * BT_W];
-        int v = (acc + (1 << 15)) >> 16;
-        out[(size_t)y * lv.bpitch + x] = (uint8_t)min(v, 255);
+    // column pass: each thread 4 adjacent columns of one row (seven 8-byte LDS reads) -> one dword store
+    {
+        const int r = tid >> 4, c0 = (tid & 15) * 4;
+        const int x = tx0 + c0, y = ty0 + r;
+        if (y < lv.h && x < lv.w) {
+            uint2 rowv[7];
+#pragma unroll
+            for (int j = 0; j < 7; j++) rowv[j] = *(const uint2*)(&s_row[(r + j) * BT_W + c0]);
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int e[7];
+#pragma unroll
+                for (int j = 0; j < 7; j++) {
+                    uint32_t wv = (k < 2) ? rowv[j].x : rowv[j].y;
+                    e[j] = (wv >> (16 * (k & 1))) & 0xFFFF;
+                }
+                int acc = g0 * (e[0] + e[6]) + g1 * (e[1] + e[5]) + g2 * (e[2] + e[4]) + g3 * e[3];
+                int v = min((acc + (1 << 15)) >> 16, 255);
+                packed |= (uint32_t)v << (8 * k);
+            }
+            uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff + (size_t)y * lv.bpitch + x;
+            *(uint32_t*)out = packed;  // bpitch is a multiple of 16 >= w: the <= 3 bytes past w land in row padding
+        }
     }
 }
 
@@ -149,12 +194,6 @@ int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
 }
 
 // ------------------------------------------------------------------ FAST ----------------------------
-// circle of radius 3, OpenCV order (dx, dy)
-__constant__ int8_t c_circ[16][2] = {{0, 3},  {1, 3},   {2, 2},   {3, 1},   {3, 0},  {3, -1}, {2, -2}, {1, -3},
-                                     {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
-
-#define FAST_CW 256  // scoring chunk width
-
 __device__ __forceinline__ bool arc9(uint32_t m) {  // 16-bit circular mask has 9 contiguous ones
     uint32_t m32 = m | (m << 16);
     uint32_t x = m32 & (m32 >> 1);
@@ -181,8 +220,14 @@ __device__ __forceinline__ int arc_score(const int d[16]) {
     return best - 1;
 }
 
+// One workgroup = one full-width strip of <= 8 rows of one level of one frame.
+//  1. the strip's pixels (+4 rows / +3 columns of halo) are staged in LDS with aligned dword loads
+//  2. FAST-9 score of every pixel of the strip and its 1-px ring -> u8 score band in LDS (0 = no corner);
+//     work is dealt to the 4 wavefronts in (row, 64-column) units
+//  3. 3x3 non-max suppression + border filter + raster-ordered compaction: each thread owns a contiguous run of
+//     the row-major strip, a block scan of the per-thread popcounts gives the output slot
 __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
-                                              uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int tile_pitch) {
+                                              uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int strip = blockIdx.x, frame = blockIdx.y;
     int L = 0;
@@ -196,69 +241,85 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     const int SW = lv.bw + 2;           // scored columns: bx0-1 .. bx0+bw
     const int xs0 = lv.bx0 - 1;
     uint8_t* s_score = smem;            // (R+2) rows x SW
-    uint8_t* s_tile = smem + (((R + 2) * SW + 15) & ~15);  // (R+8) rows x tile_pitch
+    uint8_t* s_tile = smem + score_bytes;
     __shared__ int s_wsum[4];
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int t = P.fast_threshold;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    for (int cx = 0; cx < SW; cx += FAST_CW) {
-        const int cw = min(FAST_CW, SW - cx);
-        // stage pixels: rows y0-4 .. y0+rows+3, columns xs0+cx-3 .. xs0+cx+cw+2
-        const int tw = cw + 6, th = rows + 8;
-        const int gx0 = xs0 + cx - 3, gy0 = y0 - 4;
-        __syncthreads();
-        for (int i = tid; i < tw * th; i += 256) {
-            int r = i / tw, cc = i - r * tw;
-            s_tile[r * tile_pitch + cc] = img[(size_t)(gy0 + r) * lv.pitch + gx0 + cc];
+    // ---- 1. stage pixels: rows y0-4 .. y0+rows+3, columns gx0 .. gx0+TW (gx0 = (xs0-3) rounded down to 4)
+    const int gx0 = (xs0 - 3) & ~3, lead = xs0 - 3 - gx0;
+    const int TW = (SW + 6 + lead + 3) & ~3, th = rows + 8, gy0 = y0 - 4;
+    if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {
+        const int tw4 = TW >> 2;
+        for (int r = wv; r < th; r += 4) {
+            const uint32_t* src = (const uint32_t*)(img + (size_t)(gy0 + r) * lv.pitch + gx0);
+            uint32_t* dst = (uint32_t*)(s_tile + r * TW);
+            for (int c4 = lane; c4 < tw4; c4 += 64) dst[c4] = src[c4];
         }
-        __syncthreads();
-        for (int i = tid; i < (rows + 2) * FAST_CW; i += 256) {
-            int r = i >> 8, cc = i & (FAST_CW - 1);
-            if (cc >= cw) continue;
-            const uint8_t* p = &s_tile[(r + 3) * tile_pitch + cc + 3];
-            int v = p[0];
-            int d[16];
-            uint32_t md = 0, mb = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                d[k] = v - (int)p[c_circ[k][1] * tile_pitch + c_circ[k][0]];
-                md |= (d[k] > t ? 1u : 0u) << k;
-                mb |= (d[k] < -t ? 1u : 0u) << k;
-            }
-            int sc = 0;
-            bool dark = arc9(md), bright = arc9(mb);
-            if (dark || bright) {
-                if (bright) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) d[k] = -d[k];
-                }
-                sc = arc_score(d);
-            }
-            s_score[r * SW + cx + cc] = (uint8_t)sc;
+    } else {
+        for (int r = wv; r < th; r += 4) {
+            const uint8_t* src = img + (size_t)(gy0 + r) * lv.pitch + gx0;
+            for (int cc = lane; cc < TW; cc += 64) s_tile[r * TW + cc] = (gx0 + cc < lv.w) ? src[cc] : 0;
         }
     }
     __syncthreads();
 
-    // NMS + border filter + raster-ordered compaction.  Items = rows x bw, row-major; each thread owns a
-    // contiguous run so that thread order == raster order.
+    // ---- 2. scores
+    const int nxc = (SW + 63) >> 6;
+    {
+        int r = 0, j = wv;
+        while (j >= nxc) { j -= nxc; r++; }
+        while (r < rows + 2) {
+            const int x = (j << 6) + lane;
+            if (x < SW) {
+                const uint8_t* p = &s_tile[(r + 3) * TW + x + 3 + lead];
+                const int v = p[0];
+                int d[16];
+                d[0] = v - p[3 * TW];        d[1] = v - p[3 * TW + 1];   d[2] = v - p[2 * TW + 2];   d[3] = v - p[TW + 3];
+                d[4] = v - p[3];             d[5] = v - p[-TW + 3];      d[6] = v - p[-2 * TW + 2];  d[7] = v - p[-3 * TW + 1];
+                d[8] = v - p[-3 * TW];       d[9] = v - p[-3 * TW - 1];  d[10] = v - p[-2 * TW - 2]; d[11] = v - p[-TW - 3];
+                d[12] = v - p[-3];           d[13] = v - p[TW - 3];      d[14] = v - p[2 * TW - 2];  d[15] = v - p[3 * TW - 1];
+                uint32_t md = 0, mb = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    md |= (d[k] > t ? 1u : 0u) << k;
+                    mb |= (d[k] < -t ? 1u : 0u) << k;
+                }
+                int sc = 0;
+                const bool dark = arc9(md), bright = arc9(mb);
+                if (dark || bright) {
+                    if (bright) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) d[k] = -d[k];
+                    }
+                    sc = arc_score(d);
+                }
+                s_score[r * SW + x] = (uint8_t)sc;
+            }
+            j += 4;
+            while (j >= nxc) { j -= nxc; r++; }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. NMS + border filter + raster-ordered compaction
     const int nitems = rows * lv.bw;
     const int ipt = (nitems + 255) / 256;
     const int i0 = tid * ipt;
     unsigned long long keep = 0;
-    for (int j = 0; j < ipt; j++) {
-        int i = i0 + j;
-        if (i >= nitems) break;
-        int rr = i / lv.bw, xx = i - rr * lv.bw;
-        const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
-        int sc = s[0];
-        if (sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-SW - 1] && sc > s[-SW] && sc > s[-SW + 1] && sc > s[SW - 1] &&
-            sc > s[SW] && sc > s[SW + 1])
-            keep |= 1ull << j;
+    {
+        int rr = i0 / lv.bw, xx = i0 - rr * lv.bw;
+        for (int j = 0; j < ipt && i0 + j < nitems; j++) {
+            const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
+            int sc = s[0];
+            if (sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-SW - 1] && sc > s[-SW] && sc > s[-SW + 1] && sc > s[SW - 1] &&
+                sc > s[SW] && sc > s[SW + 1])
+                keep |= 1ull << j;
+            if (++xx == lv.bw) { xx = 0; rr++; }
+        }
     }
     int cnt = __popcll(keep);
-    // block exclusive scan of cnt
-    int lane = tid & 63, wv = tid >> 6;
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -284,28 +345,30 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     if (tid == 0) strip_cnt[(size_t)frame * P.strips_per_frame + lv.strip_base + strip] = min(total, lv.strip_cap);
 }
 
-static int fast_tile_pitch() { return FAST_CW + 8; }
-
 int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
     const Plan& P = c->plan;
-    size_t lds = 0;
+    size_t score_bytes = 0, tile_bytes = 0;
     for (int L = 0; L < P.nlevels; L++) {
         const LevelInfo& v = P.lv[L];
-        size_t a = (((size_t)(v.strip_rows + 2) * (v.bw + 2) + 15) & ~(size_t)15) +
-                   (size_t)(v.strip_rows + 8) * fast_tile_pitch();
-        lds = std::max(lds, a);
+        score_bytes = std::max(score_bytes, (((size_t)(v.strip_rows + 2) * (v.bw + 2) + 15) & ~(size_t)15));
+        tile_bytes = std::max(tile_bytes, (size_t)(v.strip_rows + 8) * ((v.bw + 2 + 6 + 3 + 3) & ~3));
     }
+    size_t lds = score_bytes + tile_bytes + 16;
     if (lds > 150 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
     if (P.strips_per_frame < 1) return MO_OK;
-    hipLaunchKernelGGL(k_fast, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr,
-                       c->d_cand, c->d_strip_cnt, fast_tile_pitch());
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_fast, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+                       c->d_strip_cnt, (int)score_bytes);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_BUF_BYTES (96 * 1024)  // LDS record window: u32 FAST records, then u64 Harris records overlaid
-#define SEL_ACAP (64 * 1024 / 4)   // u32 records that fit the window (FAST pass)
+#define SEL_BUF_BYTES (48 * 1024)  // LDS record window: u32 FAST records, then u64 Harris records overlaid
 #define SEL_MAXSTRIPS 1024
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
