@@ -100,12 +100,16 @@ def find_essential_ransac8(p1, p2, K, thr_px=3.0, n_hyp=4096, seed=4096, pair=0,
     d = sampson(E, x1, x2)
     sel = d <= thr2
     tau2 = min(max(9.0 * float(d[sel].sum()) / int(sel.sum()), lo2), thr2)
+    c_prev, tau2_prev = -1, -1.0
     for _ in range(5):
         d = sampson(E, x1, x2)
         sel = d <= tau2
         c = int(sel.sum())
         if c < 8 or 2 * c < n0:
             break
+        if c == c_prev and tau2 == tau2_prev:  # same selection size at the same threshold: converged
+            break
+        c_prev, tau2_prev = c, tau2
         _, _, Vt = np.linalg.svd(_design(x1[sel], x2[sel]), full_matrices=False)
         E = project_essential(Vt[-1].reshape(3, 3))
         tau2 = min(max(9.0 * float(d[sel].sum()) / c, lo2), thr2)

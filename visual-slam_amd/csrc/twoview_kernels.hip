@@ -143,13 +143,22 @@ __device__ bool svd3_rank2(const double* E, double* U, double* V, double* sig) {
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) a[i * 3 + j] = E[0 * 3 + i] * E[0 * 3 + j] + E[1 * 3 + i] * E[1 * 3 + j] + E[2 * 3 + i] * E[2 * 3 + j];
     jacobi_eig<3>(a, v);
-    int o0 = 0, o1 = 1, o2 = 2;
-    double l[3] = {a[0], a[4], a[8]};
-    if (l[o0] < l[o1]) { int t = o0; o0 = o1; o1 = t; }
-    if (l[o1] < l[o2]) { int t = o1; o1 = o2; o2 = t; }
-    if (l[o0] < l[o1]) { int t = o0; o0 = o1; o1 = t; }
-    double v1[3] = {v[0 * 3 + o0], v[1 * 3 + o0], v[2 * 3 + o0]};
-    double v2[3] = {v[0 * 3 + o1], v[1 * 3 + o1], v[2 * 3 + o1]};
+    // sort the three eigenpairs by descending eigenvalue with compare-exchanges on registers (no dynamic indexing)
+    double l0 = a[0], l1 = a[4], l2 = a[8];
+    double c0[3] = {v[0], v[3], v[6]}, c1[3] = {v[1], v[4], v[7]}, c2[3] = {v[2], v[5], v[8]};
+#define CSWAP(la, lb, ca, cb)                                   \
+    if (la < lb) {                                              \
+        double t_ = la; la = lb; lb = t_;                       \
+        for (int i_ = 0; i_ < 3; i_++) { double u_ = ca[i_]; ca[i_] = cb[i_]; cb[i_] = u_; } \
+    }
+    CSWAP(l0, l1, c0, c1)
+    CSWAP(l1, l2, c1, c2)
+    CSWAP(l0, l1, c0, c1)
+#undef CSWAP
+    double v1[3] = {c0[0], c0[1], c0[2]};
+    double v2[3] = {c1[0], c1[1], c1[2]};
+    double l[3] = {l0, l1, l2};
+    const int o0 = 0, o1 = 1, o2 = 2;
     double s1 = sqrt(fmax(l[o0], 0.0)), s2 = sqrt(fmax(l[o1], 0.0));
     if (!(s2 > 1e-12 * s1) || !(s1 > 0)) return false;
     double u1[3], u2[3], u3[3], v3[3];
@@ -214,50 +223,61 @@ __device__ inline void sample8(uint64_t seed, int h, int m, int* idx) {
     }
 }
 
-// null vector of the 8x9 epipolar constraint matrix by Gauss-Jordan with full pivoting
+// Null vector of the 8x9 epipolar constraint matrix: Householder QR of its transpose M (9x8, column j = constraint j);
+// the last column of Q = H0 H1 .. H7 e8 spans the orthogonal complement of the 8 constraints.  No pivoting is needed
+// for an orthonormal Q, every index is a compile-time constant (the whole factorisation lives in registers), and
+// it stays well defined when E has vanishing entries (pure sideways translation: e33 = 0).
 __device__ bool eight_point(const double* pts /* [8][4] */, double* E) {
-    double A[8][9];
+    double M[9][8];
+#pragma unroll
     for (int k = 0; k < 8; k++) {
         double x1 = pts[k * 4], y1 = pts[k * 4 + 1], x2 = pts[k * 4 + 2], y2 = pts[k * 4 + 3];
-        A[k][0] = x2 * x1; A[k][1] = x2 * y1; A[k][2] = x2;
-        A[k][3] = y2 * x1; A[k][4] = y2 * y1; A[k][5] = y2;
-        A[k][6] = x1;      A[k][7] = y1;      A[k][8] = 1.0;
+        M[0][k] = x2 * x1; M[1][k] = x2 * y1; M[2][k] = x2;
+        M[3][k] = y2 * x1; M[4][k] = y2 * y1; M[5][k] = y2;
+        M[6][k] = x1;      M[7][k] = y1;      M[8][k] = 1.0;
     }
-    int colperm[9];
-    for (int j = 0; j < 9; j++) colperm[j] = j;
-    double amax0 = 0;
-    for (int r = 0; r < 8; r++) {
-        int pr = r, pc = r;
-        double best = -1;
-        for (int i = r; i < 8; i++)
-            for (int j = r; j < 9; j++) {
-                double v = fabs(A[i][j]);
-                if (v > best) { best = v; pr = i; pc = j; }
-            }
-        if (r == 0) amax0 = best;
-        if (!(best > 1e-13 * amax0)) return false;
-        if (pr != r) for (int j = 0; j < 9; j++) { double t = A[r][j]; A[r][j] = A[pr][j]; A[pr][j] = t; }
-        if (pc != r) {
-            for (int i = 0; i < 8; i++) { double t = A[i][r]; A[i][r] = A[i][pc]; A[i][pc] = t; }
-            int t = colperm[r]; colperm[r] = colperm[pc]; colperm[pc] = t;
-        }
-        double inv = 1.0 / A[r][r];
-        for (int j = r; j < 9; j++) A[r][j] *= inv;
-        for (int i = 0; i < 8; i++) {
-            if (i == r) continue;
-            double f = A[i][r];
-            if (f == 0.0) continue;
-            for (int j = r; j < 9; j++) A[i][j] -= f * A[r][j];
+    double beta[8];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        double nrm2 = 0;
+#pragma unroll
+        for (int i = k; i < 9; i++) nrm2 += M[i][k] * M[i][k];
+        double nrm = sqrt(nrm2);
+        ok = ok && (nrm > 1e-13);
+        double alpha = M[k][k] >= 0 ? -nrm : nrm;
+        double v0 = M[k][k] - alpha;           // v = x - alpha e1, stored in place of column k (rows k..8)
+        M[k][k] = v0;
+        double vtv = nrm2 - 2.0 * alpha * (v0 + alpha) + alpha * alpha;  // = |x|^2 - 2 alpha x0 + alpha^2
+        vtv = vtv > 0 ? vtv : 1.0;
+        beta[k] = 2.0 / vtv;
+#pragma unroll
+        for (int j = k + 1; j < 8; j++) {
+            double dot = 0;
+#pragma unroll
+            for (int i = k; i < 9; i++) dot += M[i][k] * M[i][j];
+            dot *= beta[k];
+#pragma unroll
+            for (int i = k; i < 9; i++) M[i][j] -= dot * M[i][k];
         }
     }
-    double e[9];
-    e[colperm[8]] = 1.0;
-    for (int r = 0; r < 8; r++) e[colperm[r]] = -A[r][8];
-    double n = 0;
-    for (int j = 0; j < 9; j++) n += e[j] * e[j];
-    n = 1.0 / sqrt(n);
-    for (int j = 0; j < 9; j++) E[j] = e[j] * n;
-    return true;
+    double n[9] = {0, 0, 0, 0, 0, 0, 0, 0, 1.0};
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        double dot = 0;
+#pragma unroll
+        for (int i = k; i < 9; i++) dot += M[i][k] * n[i];
+        dot *= beta[k];
+#pragma unroll
+        for (int i = k; i < 9; i++) n[i] -= dot * M[i][k];
+    }
+    double nn = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) nn += n[j] * n[j];
+    nn = 1.0 / sqrt(nn);
+#pragma unroll
+    for (int j = 0; j < 9; j++) E[j] = n[j] * nn;
+    return ok;
 }
 
 // ---------------------------------------------------------------- prep ----------------------------
@@ -482,6 +502,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         }
         return;
     }
+    int c_prev = -1;
+    double tau2_prev = -1.0;
     for (int it = 0; it < 5; it++) {
         double acc[45];
         for (int j = 0; j < 45; j++) acc[j] = 0;
@@ -507,6 +529,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         }
         const int c = block_sum_i(cnt, s_redi);
         if (c < 8 || 2 * c < n0) break;  // block-uniform
+        if (c == c_prev && tau2 == tau2_prev) break;  // same selection size at the same threshold: converged
+        c_prev = c; tau2_prev = tau2;
         const double sds = block_sum(sd, s_red);
         // 45 sums: wave shuffle reduction, per-wave partials in LDS, one barrier
         for (int j = 0; j < 45; j++) {
