@@ -591,14 +591,37 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
     if ((lane & 1) == 0) desc[lane >> 1] = (uint8_t)(nib | (hi << 4));
 }
 
+#define DP_RAW_PITCH 36   // 31 columns + <= 3 alignment lead-in, 9 dwords
+#define DP_BLR_PITCH 44   // 39 columns + <= 3 alignment lead-in, 11 dwords
+#define DP_WAVE_BYTES (31 * DP_RAW_PITCH + 39 * DP_BLR_PITCH)
+
+// stage a rows x ndw-dword window whose first column is x0 (rounded down to 4) into a wavefront-private LDS patch
+__device__ __forceinline__ void stage_patch(const uint8_t* img, int pitch, int x0a, int y0, int rows, int ndw, uint8_t* dst,
+                                            int dpitch, int lane, bool aligned) {
+    if (aligned) {
+        for (int i = lane; i < rows * ndw; i += 64) {
+            int r = i / ndw, c4 = i - r * ndw;
+            *(uint32_t*)(dst + r * dpitch + 4 * c4) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * c4);
+        }
+    } else {
+        for (int i = lane; i < rows * ndw * 4; i += 64) {
+            int r = i / (ndw * 4), cidx = i - r * (ndw * 4);
+            dst[r * dpitch + cidx] = (x0a + cidx < pitch) ? img[(size_t)(y0 + r) * pitch + x0a + cidx] : 0;
+        }
+    }
+}
+
+// One wavefront per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred patch (rBRIEF) are
+// staged in LDS with aligned dword loads; the orientation sums and the 256 rotated tests then read LDS only.
 __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                                   const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
                                                   int* flags) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * DP_WAVE_BYTES];
     const int frame = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wv;
     const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
     int total = 0, L = -1, idx = 0;
     for (int l = 0; l < P.nlevels; l++) {
@@ -610,17 +633,38 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         counts[frame] = total;
         if (total > cap) atomicOr(&flags[0], 2);
     }
-    if (L < 0 || k >= cap) return;
-    const LevelInfo lv = P.lv[L];
-    FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
-    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
-    const int x = fk.x, y = fk.y;
+    const bool active = L >= 0 && k < cap;  // wave-uniform
+    uint8_t* s_raw = s_patch + wv * DP_WAVE_BYTES;
+    uint8_t* s_blr = s_raw + 31 * DP_RAW_PITCH;
+    const LevelInfo lv = P.lv[active ? L : 0];
+    int x = 0, y = 0, offr = 0, offb = 0, cx = 0, cy = 0;
+    float response = 0.f, px = 0.f, py = 0.f;
+    if (active) {
+        FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
+        x = fk.x; y = fk.y; response = fk.response;
+        px = (float)x * lv.scale; py = (float)y * lv.scale;
+        const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+        const int xr0 = (x - 15) & ~3;
+        offr = (x - 15) - xr0;
+        const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
+        stage_patch(img, lv.pitch, xr0, y - 15, 31, min(9, (lv.pitch - xr0) >> 2), s_raw, DP_RAW_PITCH, lane, al_raw);
+        if (desc) {
+            float inv = 1.f / lv.scale;
+            cx = __float2int_rn(px * inv); cy = __float2int_rn(py * inv);
+            const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
+            const int xb0 = (cx - 19) & ~3;
+            offb = (cx - 19) - xb0;
+            stage_patch(bl, lv.bpitch, xb0, cy - 19, 39, min(11, (lv.bpitch - xb0) >> 2), s_blr, DP_BLR_PITCH, lane, true);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
     // intensity centroid over the radius-15 disc: one row per lane
     int m10 = 0, m01 = 0;
     if (lane < 31) {
         int v = lane - 15;
         int d = P.umax[v < 0 ? -v : v];
-        const uint8_t* row = img + (size_t)(y + v) * lv.pitch + x;
+        const uint8_t* row = s_raw + lane * DP_RAW_PITCH + 15 + offr;
         int rs = 0;
         for (int u = -d; u <= d; u++) {
             int p = row[u];
@@ -632,21 +676,20 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     float angle = fast_atan2_deg((float)m01, (float)m10);
-    float px = (float)x * lv.scale, py = (float)y * lv.scale;
     mo_keypoint* o = kps + (size_t)frame * cap + k;
     if (lane == 0) {
         o->x = px; o->y = py;
         o->size = 31 * lv.scale;
         o->angle = angle;
-        o->response = fk.response;
+        o->response = response;
         o->octave = L;
         o->class_id = -1;
     }
     if (desc) {
-        float inv = 1.f / lv.scale;
-        int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
-        const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
-        rbrief_wave<false>(bl, lv.bpitch, img, lv.pitch, lv.w, lv.h, cx, cy, angle, desc + ((size_t)frame * cap + k) * 32, lane);
+        // patch-local coordinates: centre (19 + offb, 19) inside the staged window; bounds are guaranteed by
+        // edge_threshold >= 19 + pattern radius <= 18
+        rbrief_wave<false>(s_blr, DP_BLR_PITCH, s_blr, DP_BLR_PITCH, 0, 0, 19 + offb, 19, angle,
+                           desc + ((size_t)frame * cap + k) * 32, lane);
     }
 }
 
