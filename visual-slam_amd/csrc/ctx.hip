@@ -174,7 +174,8 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
                        "only firstLevel=0, WTA_K=2, HARRIS_SCORE, patchSize=31 (the reference's values) are built");
     if (p->edge_threshold < 19 || p->edge_threshold > 1024)
         return mo_fail(c, MO_ERR_UNSUPPORTED, "edge_threshold must be >= 19 (descriptor radius)");
-    if (p->nfeatures < 1 || !(p->scale_factor > 1.0f)) return mo_fail(c, MO_ERR_ARG, "nfeatures >= 1, scale_factor > 1");
+    if (p->nfeatures < 1 || !(p->scale_factor > 1.0f) || p->scale_factor > 2.0f)
+        return mo_fail(c, MO_ERR_ARG, "nfeatures >= 1, 1 < scale_factor <= 2");
     if (p->select_order != MO_ORDER_LIBSTDCXX && p->select_order != MO_ORDER_MSVC)
         return mo_fail(c, MO_ERR_ARG, "select_order must be MO_ORDER_LIBSTDCXX or MO_ORDER_MSVC");
 

@@ -49,23 +49,70 @@ int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, ui
 }
 
 // ------------------------------------------------------------------ resize --------------------------
-__global__ void k_resize(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
-                         uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
-                         const int* __restrict__ xofs, const int* __restrict__ xc1, const int* __restrict__ yofs,
-                         const int* __restrict__ yc1) {
-    int x = blockIdx.x * 64 + threadIdx.x;
-    int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= dw || y >= dh) return;
+#define RS_TW 64
+#define RS_TH 16
+#define RS_SRC_ROWS 40    // source rows a 16-row output tile can touch (scale <= 2) + 1
+#define RS_SRC_PITCH 144  // source columns a 64-column output tile can touch (scale <= 2) + alignment lead-in
+
+// INTER_LINEAR_EXACT level L from level L-1: one workgroup = 64x16 output tile.  The source window is staged in LDS
+// with aligned dword loads, the per-column / per-row fixed-point coefficients (built on the host in cv2's double
+// arithmetic) are cached in LDS, each thread produces 4 adjacent pixels and stores one dword.
+__global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
+                                                uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
+                                                const int* __restrict__ xofs, const int* __restrict__ xc1,
+                                                const int* __restrict__ yofs, const int* __restrict__ yc1) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_SRC_ROWS * RS_SRC_PITCH];
+    __shared__ int s_xo[RS_TW], s_xc[RS_TW], s_yo[RS_TH], s_yc[RS_TH];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * RS_TW, ty0 = blockIdx.y * RS_TH;
     const uint8_t* s = src + (size_t)blockIdx.z * src_fstride;
-    int ox = xofs[x], oy = yofs[y];
-    int ox1 = min(ox + 1, sw - 1), oy1 = min(oy + 1, sh - 1);
-    uint32_t mx1 = xc1[x], mx0 = 256 - mx1, my1 = yc1[y], my0 = 256 - my1;
-    const uint8_t* r0 = s + (size_t)oy * spitch;
-    const uint8_t* r1 = s + (size_t)oy1 * spitch;
-    uint32_t h0 = mx0 * r0[ox] + mx1 * r0[ox1];
-    uint32_t h1 = mx0 * r1[ox] + mx1 * r1[ox1];
-    uint32_t v = my0 * h0 + my1 * h1;
-    dst[(size_t)blockIdx.z * dst_fstride + (size_t)y * dpitch + x] = (uint8_t)((v + 32768u) >> 16);
+    if (tid < RS_TW) {
+        int x = min(tx0 + tid, dw - 1);
+        s_xo[tid] = xofs[x];
+        s_xc[tid] = xc1[x];
+    } else if (tid < RS_TW + RS_TH) {
+        int y = min(ty0 + tid - RS_TW, dh - 1);
+        s_yo[tid - RS_TW] = yofs[y];
+        s_yc[tid - RS_TW] = yc1[y];
+    }
+    __syncthreads();
+    const int sx0 = s_xo[0], sx1 = min(s_xo[RS_TW - 1] + 1, sw - 1);
+    const int sy0 = s_yo[0], sy1 = min(s_yo[RS_TH - 1] + 1, sh - 1);
+    const int sxa = sx0 & ~3;
+    const int ncols = sx1 - sxa + 1, nrows = sy1 - sy0 + 1;
+    if (ncols > RS_SRC_PITCH || nrows > RS_SRC_ROWS) return;  // scale factor > 2: not supported by this tile shape (host checks)
+    if ((spitch & 3) == 0 && (((size_t)s) & 3) == 0) {
+        const int ndw = (ncols + 3) >> 2;
+        for (int i = tid; i < nrows * ndw; i += 256) {
+            int r = i / ndw, c4 = i - r * ndw;
+            ((uint32_t*)(s_src + r * RS_SRC_PITCH))[c4] = *(const uint32_t*)(s + (size_t)(sy0 + r) * spitch + sxa + 4 * c4);
+        }
+    } else {
+        for (int i = tid; i < nrows * ncols; i += 256) {
+            int r = i / ncols, cc = i - r * ncols;
+            s_src[r * RS_SRC_PITCH + cc] = s[(size_t)(sy0 + r) * spitch + sxa + cc];
+        }
+    }
+    __syncthreads();
+    const int ry = tid >> 4, c0 = (tid & 15) * 4;
+    const int x = tx0 + c0, y = ty0 + ry;
+    if (y >= dh || x >= dw) return;
+    const int oy = s_yo[ry] - sy0, oy1 = min(s_yo[ry] + 1, sh - 1) - sy0;
+    const uint32_t my1 = s_yc[ry], my0 = 256 - my1;
+    const uint8_t* r0 = s_src + oy * RS_SRC_PITCH;
+    const uint8_t* r1 = s_src + oy1 * RS_SRC_PITCH;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int ox = s_xo[c0 + k] - sxa, ox1 = min(s_xo[c0 + k] + 1, sw - 1) - sxa;
+        const uint32_t mx1 = s_xc[c0 + k], mx0 = 256 - mx1;
+        uint32_t h0 = mx0 * r0[ox] + mx1 * r0[ox1];
+        uint32_t h1 = mx0 * r1[ox] + mx1 * r1[ox1];
+        uint32_t v = my0 * h0 + my1 * h1;
+        packed |= ((v + 32768u) >> 16) << (8 * k);
+    }
+    // dpitch is a multiple of 16 >= dw: the <= 3 bytes past dw land in row padding
+    *(uint32_t*)(dst + (size_t)blockIdx.z * dst_fstride + (size_t)y * dpitch + x) = packed;
 }
 
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
@@ -76,8 +123,8 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels)
         const uint8_t* src = L == 1 ? d_gray : c->d_pyr + s.off;
         size_t sfs = L == 1 ? (size_t)P.w * P.h : (size_t)P.pyr_stride;
         const ResizeTab& t = c->rtab[L];
-        dim3 grid((d.w + 63) / 64, (d.h + 3) / 4, batch);
-        hipLaunchKernelGGL(k_resize, grid, dim3(64, 4), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
+        dim3 grid((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, batch);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
                            (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1);
     }
     HIPCHK(c, hipGetLastError());
@@ -220,6 +267,13 @@ __device__ __forceinline__ int arc_score(const int d[16]) {
     return best - 1;
 }
 
+// differences centre - circle pixel, OpenCV circle order
+#define FAST_LOAD_D(d, v, p, TW)                                                                              \
+    d[0] = v - p[3 * TW];   d[1] = v - p[3 * TW + 1];   d[2] = v - p[2 * TW + 2];   d[3] = v - p[TW + 3];        \
+    d[4] = v - p[3];        d[5] = v - p[-TW + 3];      d[6] = v - p[-2 * TW + 2];  d[7] = v - p[-3 * TW + 1];   \
+    d[8] = v - p[-3 * TW];  d[9] = v - p[-3 * TW - 1];  d[10] = v - p[-2 * TW - 2]; d[11] = v - p[-TW - 3];      \
+    d[12] = v - p[-3];      d[13] = v - p[TW - 3];      d[14] = v - p[2 * TW - 2];  d[15] = v - p[3 * TW - 1];
+
 // One workgroup = one full-width strip of <= 8 rows of one level of one frame.
 //  1. the strip's pixels (+4 rows / +3 columns of halo) are staged in LDS with aligned dword loads
 //  2. FAST-9 score of every pixel of the strip and its 1-px ring -> u8 score band in LDS (0 = no corner);
@@ -265,7 +319,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     }
     __syncthreads();
 
-    // ---- 2. scores
+    // ---- 2. scores (queueing the corners in LDS and scoring them densely was measured: no gain, lower occupancy)
     const int nxc = (SW + 63) >> 6;
     {
         int r = 0, j = wv;
@@ -276,10 +330,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
                 const uint8_t* p = &s_tile[(r + 3) * TW + x + 3 + lead];
                 const int v = p[0];
                 int d[16];
-                d[0] = v - p[3 * TW];        d[1] = v - p[3 * TW + 1];   d[2] = v - p[2 * TW + 2];   d[3] = v - p[TW + 3];
-                d[4] = v - p[3];             d[5] = v - p[-TW + 3];      d[6] = v - p[-2 * TW + 2];  d[7] = v - p[-3 * TW + 1];
-                d[8] = v - p[-3 * TW];       d[9] = v - p[-3 * TW - 1];  d[10] = v - p[-2 * TW - 2]; d[11] = v - p[-TW - 3];
-                d[12] = v - p[-3];           d[13] = v - p[TW - 3];      d[14] = v - p[2 * TW - 2];  d[15] = v - p[3 * TW - 1];
+                FAST_LOAD_D(d, v, p, TW)
                 uint32_t md = 0, mb = 0;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -354,11 +405,11 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
         tile_bytes = std::max(tile_bytes, (size_t)(v.strip_rows + 8) * ((v.bw + 2 + 6 + 3 + 3) & ~3));
     }
     size_t lds = score_bytes + tile_bytes + 16;
-    if (lds > 150 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
+    if (lds > 128 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
     if (P.strips_per_frame < 1) return MO_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(k_fast, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr, c->d_cand,

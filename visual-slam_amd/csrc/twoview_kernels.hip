@@ -130,6 +130,62 @@ __device__ void jacobi9_lanes(volatile double* a, volatile double* v, int lane) 
     }
 }
 
+// Smallest eigenvector of the 9x9 normal matrix N (45 upper-triangular sums, row-major order p <= q) by inverse
+// iteration on N + delta*I with an LDL^T factorisation; x holds the starting vector (the current estimate, already
+// close) and receives the result.  All indices are compile-time constants (registers).  Converges at the rate
+// lambda_9 / lambda_8 per step: a couple of steps on clean data, more on noisy data -> fixed 16 steps with an
+// early exit once the direction stops moving.
+__device__ void smallest_eigvec9(const double* Nsym, double* x) {
+    double L[9][9], D[9];
+    double tr = 0;
+#pragma unroll
+    for (int p = 0, k = 0; p < 9; p++)
+#pragma unroll
+        for (int q = p; q < 9; q++, k++) { L[q][p] = Nsym[k]; if (p == q) tr += Nsym[k]; }
+    const double delta = 1e-15 * tr + 1e-300;
+    // LDL^T in place: L[i][j] (i > j) unit lower factor, D diagonal
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        double d = L[j][j] + delta;
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
+        d = d > 1e-300 ? d : 1e-300;
+        D[j] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 9; i++) {
+            double v = L[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = v * inv;
+        }
+    }
+    double y[9];
+    for (int it = 0; it < 16; it++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) y[i] = x[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int k = 0; k < i; k++) y[i] -= L[i][k] * y[k];
+#pragma unroll
+        for (int i = 0; i < 9; i++) y[i] /= D[i];
+#pragma unroll
+        for (int i = 8; i >= 0; i--)
+#pragma unroll
+            for (int k = i + 1; k < 9; k++) y[i] -= L[k][i] * y[k];
+        double nn = 0, dot = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nn += y[i] * y[i];
+        nn = 1.0 / sqrt(nn);
+#pragma unroll
+        for (int i = 0; i < 9; i++) { y[i] *= nn; dot += y[i] * x[i]; }
+#pragma unroll
+        for (int i = 0; i < 9; i++) x[i] = y[i];
+        if (fabs(dot) > 1.0 - 1e-15) break;  // x was unit length: direction converged
+    }
+}
+
 __device__ inline void cross3(const double* a, const double* b, double* c) {
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
@@ -476,7 +532,6 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     // do not bias the algebraic fit; a refit is only accepted while >= half of the original consensus is selected.
     __shared__ double s_N[45];
     __shared__ double s_part[TV_BLOCK / 64][45];
-    __shared__ volatile double s_A9[81], s_V9[81];
     __shared__ int s_stop;
     const double lo2 = thr2 / 4096.0;
     int n0;
@@ -541,22 +596,16 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         __syncthreads();
         if (tid < 45) s_N[tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
         __syncthreads();
-        if (tid < 64) {  // wave 0: expand the symmetric matrix and diagonalise it with one lane per column
-            if (tid == 0) {
-                int k = 0;
-                for (int p = 0; p < 9; p++)
-                    for (int q = p; q < 9; q++) { s_A9[p * 9 + q] = s_N[k]; s_A9[q * 9 + p] = s_N[k]; k++; }
-            }
-            jacobi9_lanes(s_A9, s_V9, tid);
-            if (tid == 0) {
-                int mn = 0;
-                for (int i = 1; i < 9; i++) if (s_A9[i * 9 + i] < s_A9[mn * 9 + mn]) mn = i;
-                double E[9];
-                for (int i = 0; i < 9; i++) E[i] = s_V9[i * 9 + mn];
-                bool ok = project_essential(E);
-                if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
-                s_stop = ok ? 0 : 1;
-            }
+        if (tid == 0) {  // smallest eigenvector of the normal matrix, seeded with the current estimate
+            double E[9], Nn[45], en = 0;
+            for (int i = 0; i < 45; i++) Nn[i] = s_N[i];
+            for (int i = 0; i < 9; i++) { E[i] = s_E[i]; en += E[i] * E[i]; }
+            en = 1.0 / sqrt(en);
+            for (int i = 0; i < 9; i++) E[i] *= en;
+            smallest_eigvec9(Nn, E);
+            bool ok = project_essential(E);
+            if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
+            s_stop = ok ? 0 : 1;
         }
         __syncthreads();
         if (s_stop) break;
