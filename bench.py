@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per rank per step")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches (HIP streams) per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     args = ap.parse_args()
@@ -142,37 +143,61 @@ def main():
     frames = make_frames(torch, dev, first, nb)
     K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])  # configs/monocular.yaml:3
 
-    ctx = V.Context(device=local, max_w=W, max_h=H, max_batch=nb)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     prm = V.orb_params(nfeatures=NFEAT, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=7,
                        select_order=V.ORDER_LIBSTDCXX)
-    kps = torch.zeros((nb, CAP, 7), dtype=torch.float32, device=dev)   # 28-byte mo_keypoint records
-    desc = torch.zeros((nb, CAP, 32), dtype=torch.uint8, device=dev)
-    counts = torch.zeros(nb, dtype=torch.int32, device=dev)
-    midx = torch.zeros((nb - 1, CAP, 2), dtype=torch.int32, device=dev)
-    mdist = torch.zeros((nb - 1, CAP, 2), dtype=torch.int32, device=dev)
-    mpass = torch.zeros((nb - 1, CAP), dtype=torch.uint8, device=dev)
-    pose = torch.zeros((nb - 1, 12), dtype=torch.float64, device=dev)
     pts = torch.zeros((B, CAP, 3), dtype=torch.float32, device=dev)  # rank 0 fills B-1 pairs, the others B
-    npts = torch.zeros(nb - 1, dtype=torch.int32, device=dev)
-    io = V.BatchIO()
-    io.d_gray = frames.data_ptr(); io.w = W; io.h = H; io.batch = nb; io.cap = CAP
-    io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = N_HYP; io.seed = 4096
-    for i in range(9):
-        io.K[i] = float(K.reshape(9)[i])
-    io.d_kps = kps.data_ptr(); io.d_desc = desc.data_ptr(); io.d_counts = counts.data_ptr()
-    io.d_match_idx = midx.data_ptr(); io.d_match_dist = mdist.data_ptr(); io.d_match_pass = mpass.data_ptr()
-    io.d_pose = pose.data_ptr(); io.d_points = pts.data_ptr(); io.d_n_points = npts.data_ptr()
+    npts = torch.zeros(B, dtype=torch.int32, device=dev)
 
+    class SubBatch:
+        """A contiguous run of this rank's pairs [p0, p1) = frames [p0, p1] on its own HIP stream and context.
+        Adjacent sub-batches share one frame (re-extracted, like the inter-rank halo); concurrent streams let the
+        latency-bound kernels of one sub-batch (selection replay, two-view refit) overlap the VALU-bound ones of
+        the other."""
+
+        def __init__(self, p0, p1):
+            self.p0, self.p1, n = p0, p1, p1 - p0 + 1
+            self.stream = torch.cuda.Stream(device=dev)
+            self.ctx = V.Context(device=local, max_w=W, max_h=H, max_batch=n)
+            self.ctx.set_stream(self.stream.cuda_stream)
+            self.kps = torch.zeros((n, CAP, 7), dtype=torch.float32, device=dev)   # 28-byte mo_keypoint records
+            self.desc = torch.zeros((n, CAP, 32), dtype=torch.uint8, device=dev)
+            self.counts = torch.zeros(n, dtype=torch.int32, device=dev)
+            self.midx = torch.zeros((n - 1, CAP, 2), dtype=torch.int32, device=dev)
+            self.mdist = torch.zeros((n - 1, CAP, 2), dtype=torch.int32, device=dev)
+            self.mpass = torch.zeros((n - 1, CAP), dtype=torch.uint8, device=dev)
+            self.pose = torch.zeros((n - 1, 12), dtype=torch.float64, device=dev)
+            io = V.BatchIO()
+            io.d_gray = frames[p0:].data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
+            io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = N_HYP; io.seed = 4096
+            for i in range(9):
+                io.K[i] = float(K.reshape(9)[i])
+            io.d_kps = self.kps.data_ptr(); io.d_desc = self.desc.data_ptr(); io.d_counts = self.counts.data_ptr()
+            io.d_match_idx = self.midx.data_ptr(); io.d_match_dist = self.mdist.data_ptr()
+            io.d_match_pass = self.mpass.data_ptr(); io.d_pose = self.pose.data_ptr()
+            io.d_points = pts[p0:].data_ptr(); io.d_n_points = npts[p0:].data_ptr()
+            self.io = io
+
+        def launch(self):
+            self.ctx._check(self.ctx.lib.mo_dev_frontend_batch(self.ctx.h, C.byref(prm), C.byref(self.io)))
+
+    S = max(1, min(args.streams, n_pairs))
+    cuts = [round(j * n_pairs / S) for j in range(S + 1)]
+    subs = [SubBatch(cuts[j], cuts[j + 1]) for j in range(S)]
+    main = torch.cuda.current_stream()
     stage_acc = {}
 
     def step(collect):
-        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        for sb in subs:
+            sb.stream.wait_stream(main)
+            sb.launch()
+        for sb in subs:
+            main.wait_stream(sb.stream)
         if world > 1:  # final map-point gather (the only collective on the path)
             gather_map_points(pts, n_pairs, dst=0)
         if collect:
-            for name, ms in ctx.stage_times():
-                stage_acc[name] = stage_acc.get(name, 0.0) + ms
+            for sb in subs:
+                for name, ms in sb.ctx.stage_times():
+                    stage_acc[name] = stage_acc.get(name, 0.0) + ms
 
     for _ in range(args.warmup):
         step(False)
@@ -197,15 +222,17 @@ def main():
         total_frames = world * B * args.steps
         ms_step = elapsed / args.steps * 1e3
         value = total_frames / elapsed
-        cnt = counts.cpu().numpy()
-        npt = npts.cpu().numpy()
+        cnt = torch.cat([sb.counts for sb in subs]).cpu().numpy()
+        npt = npts[:n_pairs].cpu().numpy()
+        mpass_mean = float(torch.cat([sb.mpass for sb in subs]).sum(dim=1).float().mean().item())
         # roofline of the dominant kernel (largest share of device time), algorithmic bytes / measured duration
         per_stage = {k: v / args.steps for k, v in stage_acc.items()}
         dom = max(per_stage, key=per_stage.get)
-        units = (nb - 1) if dom in ("match_knn2_ratio", "two_view") else nb
+        n_ext = sum(sb.io.batch for sb in subs)  # frames extracted per step (sub-batches share one frame each)
+        units = n_pairs if dom in ("match_knn2_ratio", "two_view") else n_ext
         alg_bytes = STAGE_BYTES.get(dom, 0) * units
         achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
-        total_alg = sum(STAGE_BYTES.get(k, 0) * ((nb - 1) if k in ("match_knn2_ratio", "two_view") else nb) for k in per_stage)
+        total_alg = sum(STAGE_BYTES.get(k, 0) * (n_pairs if k in ("match_knn2_ratio", "two_view") else n_ext) for k in per_stage)
         out = {
             "metric": "frames/sec (extract+match+pose) at 640x480, 2000 ORB",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,8 +241,8 @@ def main():
             "config": {"workload": "batch of %d synthetic 640x480 frames per GPU: ORB extract (2000 feat, 8 levels, FAST-7) "
                                    "+ BF-Hamming 2-NN ratio 0.75 on consecutive pairs + 8-pt E RANSAC (%d hyp) pose/DLT per pair"
                                    % (B, N_HYP),
-                       "frames_per_gpu": B, "n_features": NFEAT, "hypotheses": N_HYP,
-                       "keypoints_per_frame_mean": float(cnt.mean()), "matches_per_pair_mean": float(mpass.sum(dim=1).float().mean().item()),
+                       "frames_per_gpu": B, "streams_per_gpu": S, "n_features": NFEAT, "hypotheses": N_HYP,
+                       "keypoints_per_frame_mean": float(cnt.mean()), "matches_per_pair_mean": mpass_mean,
                        "map_points_per_pair_mean": float(npt.mean()),
                        "parallelism": "frame-sharded x%d, RCCL gather of map points" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
@@ -232,7 +259,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for sb in subs:
+        sb.ctx.close()
 
 
 if __name__ == "__main__":
