@@ -233,6 +233,14 @@ def main():
         alg_bytes = STAGE_BYTES.get(dom, 0) * units
         achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
         total_alg = sum(STAGE_BYTES.get(k, 0) * (n_pairs if k in ("match_knn2_ratio", "two_view") else n_ext) for k in per_stage)
+        traffic = None  # HBM bytes per step of the dominant stage from the committed PMC passes (same command, batch 256)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("batch_frames") == B and S == 1 and dom in pmc["per_stage"]:
+                traffic = pmc["per_stage"][dom]["hbm_bytes"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "frames/sec (extract+match+pose) at 640x480, 2000 ORB",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -246,7 +254,8 @@ def main():
                        "map_points_per_pair_mean": float(npt.mean()),
                        "parallelism": "frame-sharded x%d, RCCL gather of map points" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": traffic,
+                         "algorithmic_bytes": alg_bytes,
                          "kernel_ms": round(per_stage[dom], 4),
                          "pipeline_achieved": round(total_alg / (ms_step * 1e-3) / 1e9, 2),
                          "note": "algorithmic bytes (SURVEY 8d) of the dominant stage / its hipEvent time; the path is "
