@@ -79,6 +79,14 @@ int mo_orb_detect_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int
 int mo_orb_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int w, int h, int stride, int ch,
                    const mo_keypoint* kps_in, int n_in, int32_t* kept_idx, uint8_t* desc, int* n_out);
 
+/* Replaces the 64 cv2.goodFeaturesToTrack(image, maxCorners = n_features // 64, qualityLevel 0.01, minDistance 10,
+ * mask = grid cell) calls of ORBExtractor.distribute_keypoints (extractor.py:104-136): 8x8 grid, Shi-Tomasi minimum
+ * eigenvalue (blockSize 3, Sobel 3), corners in cell-major order, best first inside a cell.
+ * xy [64 * (n_features / 64)][2] pixel coordinates; n_out = number of corners.  Descriptors for them come from
+ * mo_orb_compute with angle -1 (extractor.py:135,140). */
+int mo_orb_grid_good_features(mo_ctx*, const uint8_t* img, int w, int h, int stride, int ch, int n_features, float* xy,
+                              int* n_out);
+
 /* ---- DescriptorMatcher ------------------------------------------------------------------- */
 /* Replaces BFMatcher(NORM_HAMMING).knnMatch(d1, d2, k=2) + the Lowe ratio loop (matcher.py:70,73-81).
  * q [batch][nq][32], t [batch][nt][32]; ratio NULL = no ratio test (ratio_test=False).
@@ -148,6 +156,7 @@ int mo_dbg_pyramid_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int
                          uint8_t* out /* lw*lh */, int* lw, int* lh);
 int mo_dbg_fast_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level,
                       int32_t* xys /* [cap][3] */, int cap, int* n);
+int mo_dbg_min_eigen(mo_ctx*, const uint8_t* gray, int w, int h, float* eig /* [h*w] */);
 int mo_dbg_retain_best(mo_ctx*, const float* resp, int n, int n_points, int select_order, int32_t* order, int* n_out);
 
 #ifdef __cplusplus

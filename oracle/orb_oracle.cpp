@@ -605,6 +605,100 @@ void compute_descriptors(const std::vector<Img>& pyr, const std::vector<float>& 
     }
 }
 
+// ---- cornerMinEigenVal(blockSize 3, Sobel 3) + goodFeaturesToTrack on one masked cell -------------------
+// Restates cv2.goodFeaturesToTrack(image, maxCorners, qualityLevel, minDistance, mask) as the reference calls it once
+// per 8x8 grid cell (src/orbslam2/extractor.py:115-129).  PARITY UNPINNED against cv2: no fixture holds these corners
+// and cv2's own float pipeline is CPU-dependent in the last bit (FMA in the AVX2 filter dispatch, running double
+// sums in boxFilter).  The arithmetic order fixed here (and mirrored by the HIP kernels) is the SSE-baseline one:
+//   Dx = (R[y-1] + R[y+1]) * s + R[y] * (2s),  R = src[x+1] - src[x-1]                 (s = (float)(1/3060))
+//   Dy = C[y+1] - C[y-1],                       C = ((s*src[x-1]) + (2s)*src[x]) + s*src[x+1]
+//   cov = (Dx*Dx, Dx*Dy, Dy*Dy) in f32; 3x3 box sum accumulated in f64, rounded once to f32 (BORDER_REFLECT_101)
+//   eig = (a + c) - sqrtf((a - c)*(a - c) + b*b),  a = 0.5f*cxx, b = cxy, c = 0.5f*cyy
+void min_eigen_map(const Img& g, std::vector<float>& eig) {
+    const int w = g.w, h = g.h;
+    const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    const float f1 = (float)(1.0f * scale_d), f0 = (float)(2.0f * scale_d);
+    std::vector<float> dx((size_t)w * h), dy((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const uint8_t* rm = g.row(reflect101(y - 1, h));
+        const uint8_t* r0 = g.row(y);
+        const uint8_t* rp = g.row(reflect101(y + 1, h));
+        for (int x = 0; x < w; x++) {
+            int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+            float Rm = (float)((int)rm[xp] - (int)rm[xm]), R0 = (float)((int)r0[xp] - (int)r0[xm]),
+                  Rp = (float)((int)rp[xp] - (int)rp[xm]);
+            float t = Rm + Rp;
+            float u = t * f1;
+            float v = R0 * f0;
+            dx[(size_t)y * w + x] = u + v;
+            float Cm = ((f1 * (float)rm[xm]) + f0 * (float)rm[x]) + f1 * (float)rm[xp];
+            float Cp = ((f1 * (float)rp[xm]) + f0 * (float)rp[x]) + f1 * (float)rp[xp];
+            dy[(size_t)y * w + x] = Cp - Cm;
+        }
+    }
+    eig.assign((size_t)w * h, 0.f);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            double sxx = 0, sxy = 0, syy = 0;
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++) {
+                    size_t o = (size_t)reflect101(y + j, h) * w + reflect101(x + i, w);
+                    float a = dx[o], b = dy[o];
+                    float xx = a * a, xy = a * b, yy = b * b;
+                    sxx += (double)xx; sxy += (double)xy; syy += (double)yy;
+                }
+            float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+            float amc = a - c;
+            float rad = amc * amc + b * b;
+            eig[(size_t)y * w + x] = (a + c) - std::sqrt(rad);
+        }
+}
+
+struct GfttCand { float val; int pos; };
+
+int good_features_cell(const std::vector<float>& eig, int w, int h, int x0, int y0, int x1, int y1, int max_corners,
+                       double quality, double min_distance, float* out_xy) {
+    float maxv = -FLT_MAX;
+    bool any = false;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) { maxv = std::max(maxv, eig[(size_t)y * w + x]); any = true; }
+    if (!any) return 0;
+    double maxVal = maxv > 0 ? (double)maxv : 0.0;  // minMaxLoc; negative maxima only arise from rounding noise
+    const float thr = (float)(maxVal * quality);
+    auto tz = [&](int y, int x) { float v = eig[(size_t)y * w + x]; return v > thr ? v : 0.f; };  // THRESH_TOZERO
+    std::vector<GfttCand> cands;
+    for (int y = std::max(y0, 1); y < std::min(y1, h - 1); y++)
+        for (int x = std::max(x0, 1); x < std::min(x1, w - 1); x++) {
+            float v = tz(y, x);
+            if (v == 0) continue;
+            float m = v;
+            for (int j = -1; j <= 1; j++)
+                for (int i = -1; i <= 1; i++) m = std::max(m, tz(y + j, x + i));
+            if (v == m) cands.push_back({v, y * w + x});
+        }
+    std::sort(cands.begin(), cands.end(), [](const GfttCand& a, const GfttCand& b) {
+        return a.val > b.val ? true : a.val < b.val ? false : a.pos > b.pos;  // greaterThanPtr: ties -> higher address
+    });
+    int n = 0;
+    const float md2 = (float)(min_distance * min_distance);
+    std::vector<float> acc;
+    for (const GfttCand& c : cands) {
+        int y = c.pos / w, x = c.pos - y * w;
+        bool good = true;
+        if (min_distance >= 1)
+            for (size_t j = 0; j < acc.size(); j += 2) {
+                float dx = (float)x - acc[j], dy = (float)y - acc[j + 1];
+                if (dx * dx + dy * dy < md2) { good = false; break; }
+            }
+        if (!good) continue;
+        acc.push_back((float)x); acc.push_back((float)y);
+        out_xy[2 * n] = (float)x; out_xy[2 * n + 1] = (float)y;
+        n++;
+        if (max_corners > 0 && n == max_corners) break;
+    }
+    return n;
+}
+
 Img wrap_gray(const uint8_t* g, int w, int h) {
     Img im(w, h);
     std::memcpy(im.px.data(), g, (size_t)w * h);
@@ -743,6 +837,29 @@ int orc_orb_compute(const uint8_t* gray, int w, int h, const orc_orb_params* p, 
     for (size_t i = 0; i < keep.size(); i++) kept_idx[i] = keep[i];
     if (!kk.empty()) compute_descriptors(pyr, scales, kk, desc);
     return (int)kk.size();
+}
+
+// min-eigenvalue map (cornerMinEigenVal, blockSize 3, Sobel 3) of a gray image -> eig [h*w] f32
+void orc_min_eigen(const uint8_t* gray, int w, int h, float* eig) {
+    Img g = wrap_gray(gray, w, h);
+    std::vector<float> e;
+    min_eigen_map(g, e);
+    std::memcpy(eig, e.data(), e.size() * sizeof(float));
+}
+
+// ORBExtractor.distribute_keypoints corner stage (extractor.py:104-136): 8x8 grid, per cell goodFeaturesToTrack(
+// maxCorners = n_features // 64, qualityLevel 0.01, minDistance 10, mask = cell); corners in cell-major order.
+// xy [64 * per_cell][2]; returns the number of corners.
+int orc_grid_good_features(const uint8_t* gray, int w, int h, int n_features, float* xy) {
+    Img g = wrap_gray(gray, w, h);
+    std::vector<float> e;
+    min_eigen_map(g, e);
+    const int rows = 8, cols = 8, ch = h / rows, cw = w / cols, per_cell = n_features / (rows * cols);
+    int n = 0;
+    for (int i = 0; i < rows; i++)
+        for (int j = 0; j < cols; j++)
+            n += good_features_cell(e, w, h, j * cw, i * ch, (j + 1) * cw, (i + 1) * ch, per_cell, 0.01, 10.0, xy + 2 * n);
+    return n;
 }
 
 // BFMatcher(NORM_HAMMING).knnMatch(k=2): per query the two smallest (distance, trainIdx) pairs,

@@ -160,3 +160,20 @@ def ratio_test(idx, dist, ratio, enabled=True):
     lib().orc_ratio_test(idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p), nq,
                          C.c_double(float(ratio)), int(bool(enabled)), out.ctypes.data_as(C.c_void_p))
     return out.astype(bool)
+
+
+def min_eigen(gray):
+    gray, p = _u8(gray)
+    h, w = gray.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_min_eigen(p, w, h, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def grid_good_features(gray, n_features=2000):
+    """corner stage of ORBExtractor.distribute_keypoints -> (N,2) float32 (x, y), cell-major order"""
+    gray, p = _u8(gray)
+    h, w = gray.shape
+    out = np.empty((64 * max(n_features // 64, 1), 2), np.float32)
+    n = lib().orc_grid_good_features(p, w, h, int(n_features), out.ctypes.data_as(C.c_void_p))
+    return out[:n].copy()

@@ -53,8 +53,6 @@ def test_compute_keeps_reference_quirk():
     kps = [KeyPoint(100.0, 100.0, 31), KeyPoint(5.0, 5.0, 31), KeyPoint(320.5, 240.5, 31)]
     out_kps, desc = ex.compute(a, kps)
     assert out_kps is kps and desc.shape == (2, 32)
-    with pytest.raises(NotImplementedError):
-        ex.extract_features(a)  # distributed=True default -> grid Shi-Tomasi, next scope row
     k2, d2 = ex.extract_features(a, distributed=False)
     assert len(k2) > 1500
 
@@ -149,3 +147,65 @@ def test_batched_device_mode_equals_host_api():
             assert np.allclose(X[q_of[r["pose_mask"]]], r["X"][r["pose_mask"]], rtol=1e-5, atol=1e-6)
             assert np.isnan(X[:n][~np.isin(np.arange(n), q_of[r["pose_mask"]])]).all()
     ctx.close(); host.close()
+
+
+def test_distribute_keypoints_like_tracker():
+    """tracker.py:87 calls extract_features(frame) -> distribute_keypoints (extractor.py:85-144): grid Shi-Tomasi corners
+    + orb.compute at angle -1.  Corners and descriptors equal the CPU oracle bit for bit."""
+    import vslam_amd as V
+    from oracle import orb_oracle as O
+    from orbslam2.extractor import ORBExtractor
+    a, _ = _pair()
+    ex = ORBExtractor(n_features=2000)
+    kps, desc = ex.extract_features(a)  # distributed=True is the default
+    exy = O.grid_good_features(a, 2000)
+    assert len(kps) == len(exy) > 500
+    assert np.array_equal(np.array([k.pt for k in kps], np.float32), exy)
+    assert all(k.size == 31 and k.angle == -1 and k.octave == 0 for k in kps)
+    kin = np.zeros(len(exy), V.KP_DTYPE)
+    kin["x"], kin["y"], kin["size"], kin["angle"], kin["class_id"] = exy[:, 0], exy[:, 1], 31, -1, -1
+    kept, edesc = O.compute(a, O.params(), kin)
+    assert np.array_equal(desc, edesc) and len(desc) <= len(kps)
+    # min-eigenvalue map itself, including the reflected borders
+    ctx = V.default_context()
+    assert np.array_equal(ctx.dbg_min_eigen(a), O.min_eigen(a))
+    odd = a[:333, :257].copy()
+    assert np.array_equal(ctx.dbg_min_eigen(odd), O.min_eigen(odd))
+    assert np.array_equal(ctx.grid_good_features(odd, 640), O.grid_good_features(odd, 640))
+    flat = np.full((480, 640), 77, np.uint8)
+    fk, fd = ex.distribute_keypoints(flat)
+    assert fk == [] and fd is None
+    kc, dc = ex.distribute_keypoints(np.repeat(a[:, :, None], 3, axis=2), n_features=640)  # colour input, override count
+    assert len(kc) == len(O.grid_good_features(a, 640))
+
+
+def test_tracker_call_sequence():
+    """The call sequence of the reference's Tracker.process_frame (tracker.py:73-146, 148-196, 198-266) driven by a small
+    harness with the drop-in classes: frame 0 -> set_first_frame, frame 1 -> initialize, frame 2 -> match + filters."""
+    from orbslam2.extractor import ORBExtractor
+    from orbslam2.initializer import MapInitializer
+    from orbslam2.matcher import DescriptorMatcher
+    K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])
+    base = np.concatenate([synthetic_frame(41), synthetic_frame(42)], axis=1)
+    frames = [np.ascontiguousarray(base[:, 5 * i:5 * i + 640]) for i in range(3)]
+    extractor = ORBExtractor(n_features=2000)                                      # tracker.py:35
+    matcher = DescriptorMatcher(matcher_type='bruteforce-hamming', ratio_threshold=0.75)   # tracker.py:38-41
+    initializer = MapInitializer(K)                                                # tracker.py:43
+    kp0, d0 = extractor.extract_features(frames[0])                                # tracker.py:87 (distributed=True)
+    # the reference's own quirk: keypoints (all corners) and descriptor rows (border-filtered) may differ in length
+    assert len(kp0) >= len(d0) > 300
+    kp0, d0 = extractor.extract_features(frames[0], distributed=False)
+    initializer.set_first_frame(kp0, d0, frames[0])                                # tracker.py:162
+    kp1, d1 = extractor.extract_features(frames[1], distributed=False)
+    ok, R, t, pts, matches = initializer.initialize(kp1, d1, matcher, frames[1])   # tracker.py:168-170
+    assert isinstance(ok, bool) and len(matches) > 300
+    if ok:
+        assert R.shape == (3, 3) and t.shape == (3, 1) and abs(np.linalg.det(R) - 1) < 1e-9
+        assert abs(np.linalg.norm(t) - 1) < 1e-9 and len(pts) == len(matches)
+    kp2, d2 = extractor.extract_features(frames[2], distributed=False)
+    m = matcher.match(d1, d2)                                                      # tracker.py:214
+    m = matcher.filter_matches_by_geometric_distance(kp1, kp2, m, 0.02, frames[2].shape)   # tracker.py:221
+    m = matcher.filter_matches_by_distance(m)                                      # tracker.py:230
+    assert len(m) > 100
+    d = np.array([np.array(kp2[x.trainIdx].pt) - np.array(kp1[x.queryIdx].pt) for x in m])
+    assert np.abs(np.median(d[:, 0]) + 5) < 1.0 and np.abs(np.median(d[:, 1])) < 1.0   # the 5 px pan is recovered

@@ -52,3 +52,21 @@ def test_libstdcxx_order_same_set():
     ra = {(o, x, y): bytes(d) for o, x, y, d in zip(a["octave"], a["x"], a["y"], da)}
     rb = {(o, x, y): bytes(d) for o, x, y, d in zip(b["octave"], b["x"], b["y"], db)}
     assert ra == rb
+
+
+def test_grid_good_features_properties():
+    """Oracle restatement of the distribute_keypoints corner stage (extractor.py:104-136): structural properties."""
+    from tests.helpers import synthetic_frame
+    img = synthetic_frame(5)
+    xy = O.grid_good_features(img, 2000)
+    assert 500 < len(xy) <= 64 * 31
+    cells = (xy[:, 1].astype(int) // 60) * 8 + xy[:, 0].astype(int) // 80
+    assert (np.diff(cells) >= 0).all()  # cell-major order
+    eig = O.min_eigen(img)
+    for c in np.unique(cells):
+        p = xy[cells == c]
+        assert len(p) <= 31
+        q = eig[p[:, 1].astype(int), p[:, 0].astype(int)]
+        assert (np.diff(q) <= 0).all()  # best first inside a cell
+        d = np.linalg.norm(p[:, None] - p[None], axis=2) + np.eye(len(p)) * 100
+        assert d.min() >= 10  # minDistance

@@ -165,6 +165,57 @@ extern "C" int mo_orb_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* 
     return MO_OK;
 }
 
+static int gftt_run(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int ch, int n_features, float* xy, int* n_out,
+                    float* eig_out) {
+    if (w < 64 || h < 64 || w > c->max_w || h > c->max_h) return mo_fail(c, MO_ERR_ARG, "image size outside the context limits");
+    if (n_features < 64) return mo_fail(c, MO_ERR_ARG, "n_features must be >= 64 (8x8 grid)");
+    const uint8_t* d_gray = nullptr;
+    int rc = stage_images(c, img, w, h, stride, ch, 1, &d_gray);
+    if (rc) return rc;
+    const int per_cell = n_features / 64;
+    size_t eig_b = (size_t)w * h * sizeof(float), xy_b = (size_t)64 * per_cell * 2 * sizeof(float);
+    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, eig_b + xy_b + 64 * sizeof(int) + 64))) return rc;
+    float* d_eig = (float*)c->d_tmp;
+    float* d_xy = (float*)((uint8_t*)c->d_tmp + eig_b);
+    int* d_n = (int*)((uint8_t*)d_xy + xy_b);
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    mo_stage_begin(c);
+    if ((rc = gftt_launch(c, d_gray, w, h, n_features, d_eig, d_xy, d_n))) return rc;
+    mo_stage_mark(c, "grid_good_features");
+    if (eig_out) HIPCHK(c, hipMemcpyAsync(eig_out, d_eig, eig_b, hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> hxy((size_t)64 * per_cell * 2);
+    int hn[64];
+    HIPCHK(c, hipMemcpyAsync(hxy.data(), d_xy, xy_b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hn, d_n, sizeof(hn), hipMemcpyDeviceToHost, c->stream));
+    int f[4];
+    HIPCHK(c, hipMemcpyAsync(f, c->d_flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (f[0] & 4) return mo_fail(c, MO_ERR_CAPACITY, "more than 4096 local maxima in one grid cell");
+    int n = 0;
+    if (xy)
+        for (int cell = 0; cell < 64; cell++)
+            for (int i = 0; i < hn[cell]; i++, n++) {
+                xy[2 * n] = hxy[((size_t)cell * per_cell + i) * 2];
+                xy[2 * n + 1] = hxy[((size_t)cell * per_cell + i) * 2 + 1];
+            }
+    if (n_out) *n_out = n;
+    return MO_OK;
+}
+
+extern "C" int mo_orb_grid_good_features(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int ch, int n_features,
+                                         float* xy, int* n_out) {
+    if (!c) return MO_ERR_ARG;
+    if (!img || !xy || !n_out) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    return gftt_run(c, img, w, h, stride, ch, n_features, xy, n_out, nullptr);
+}
+
+extern "C" int mo_dbg_min_eigen(mo_ctx* c, const uint8_t* gray, int w, int h, float* eig) {
+    if (!c) return MO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    return gftt_run(c, gray, w, h, w, 1, 64, nullptr, nullptr, eig);
+}
+
 extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const uint8_t* t, int nt, const double* ratio,
                                    int batch, int32_t* train_idx, int32_t* dist, uint8_t* pass) {
     if (!c) return MO_ERR_ARG;

@@ -136,6 +136,8 @@ int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points,
 int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t q_stride, size_t t_stride,
                        const int32_t* d_counts, const int32_t* d_qf, const int32_t* d_tf, int nq_fixed, int nt_fixed,
                        int n_pairs, int out_stride, double ratio, int32_t* d_idx, int32_t* d_dist, uint8_t* d_pass);
+// gftt_kernels.hip
+int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, float* d_eig, float* d_xy, int* d_n);
 // twoview_kernels.hip
 struct TwoViewArgs {
     int n_pairs, cap, n_hyp;

@@ -1,0 +1,177 @@
+// gftt_kernels.hip -- grid Shi-Tomasi corners for ORBExtractor.distribute_keypoints (gfx950).
+// Replaces the 64 x cv2.goodFeaturesToTrack(image, maxCorners = n // 64, qualityLevel 0.01, minDistance 10, mask = cell)
+// calls of the reference (src/orbslam2/extractor.py:115-129): the min-eigenvalue map is computed ONCE per frame
+// (the reference recomputes it for every cell), then one workgroup per grid cell thresholds at 1 % of the cell's
+// maximum, keeps 3x3 local maxima, sorts them by (quality desc, address desc) and runs the greedy min-distance pick.
+// Float arithmetic order is the one fixed in oracle/orb_oracle.cpp (min_eigen_map); compile with -ffp-contract=off.
+#include <cfloat>
+
+#include "common.h"
+
+__device__ __forceinline__ int gf_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+#define ME_TW 32
+#define ME_TH 8
+
+// cornerMinEigenVal(blockSize 3, Sobel 3, BORDER_REFLECT_101): u8 tile (+2 halo) -> Dx, Dy (+1 halo) -> 3x3 box of the
+// covariance terms in f64 -> (a + c) - sqrt((a - c)^2 + b^2)
+__global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ gray, int w, int h, float* __restrict__ eig) {
+    __shared__ float s_dx[(ME_TH + 2) * (ME_TW + 2)], s_dy[(ME_TH + 2) * (ME_TW + 2)];
+    const int tx0 = blockIdx.x * ME_TW, ty0 = blockIdx.y * ME_TH, tid = threadIdx.x;
+    // Dx/Dy are needed at (reflected) coordinates y-1..y+1, x-1..x+1 of the output pixel; each of those needs pixels at
+    // its own +-1 (reflected again).  Evaluate them directly from global memory with both reflections (L2-resident).
+    const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    const float f1 = (float)(1.0f * scale_d), f0 = (float)(2.0f * scale_d);
+    for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
+        int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
+        int y = gf_reflect101(ty0 + r - 1, h), x = gf_reflect101(tx0 + c - 1, w);
+        const uint8_t* rm = gray + (size_t)gf_reflect101(y - 1, h) * w;
+        const uint8_t* r0 = gray + (size_t)y * w;
+        const uint8_t* rp = gray + (size_t)gf_reflect101(y + 1, h) * w;
+        int xm = gf_reflect101(x - 1, w), xp = gf_reflect101(x + 1, w);
+        float Rm = (float)((int)rm[xp] - (int)rm[xm]), R0 = (float)((int)r0[xp] - (int)r0[xm]),
+              Rp = (float)((int)rp[xp] - (int)rp[xm]);
+        float t = Rm + Rp;
+        float u = t * f1;
+        float v = R0 * f0;
+        s_dx[i] = u + v;
+        float Cm = ((f1 * (float)rm[xm]) + f0 * (float)rm[x]) + f1 * (float)rm[xp];
+        float Cp = ((f1 * (float)rp[xm]) + f0 * (float)rp[x]) + f1 * (float)rp[xp];
+        s_dy[i] = Cp - Cm;
+    }
+    __syncthreads();
+    const int lx = tid & 31, ly = tid >> 5;
+    const int x = tx0 + lx, y = ty0 + ly;
+    if (x >= w || y >= h) return;
+    double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            float a = s_dx[(ly + j) * (ME_TW + 2) + lx + i], b = s_dy[(ly + j) * (ME_TW + 2) + lx + i];
+            float xx = a * a, xy = a * b, yy = b * b;
+            sxx += (double)xx; sxy += (double)xy; syy += (double)yy;
+        }
+    float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+    float amc = a - c;
+    float rad = amc * amc + b * b;
+    eig[(size_t)y * w + x] = (a + c) - sqrtf(rad);
+}
+
+#define GF_CAP 4096       // local maxima per cell held in LDS
+#define GF_MAXCORNERS 256
+
+// one workgroup per grid cell
+__global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig, int w, int h, int cols, int cw, int ch,
+                                                   int max_corners, double quality, double min_dist, float* __restrict__ out_xy,
+                                                   int* __restrict__ out_n, int* flags) {
+    __shared__ unsigned long long s_key[GF_CAP];
+    __shared__ float s_red[4];
+    __shared__ int s_n;
+    __shared__ float s_ax[GF_MAXCORNERS], s_ay[GF_MAXCORNERS];
+    const int cell = blockIdx.x, ci = cell / cols, cj = cell - ci * cols;
+    const int x0 = cj * cw, y0 = ci * ch, x1 = x0 + cw, y1 = y0 + ch;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // 1. cell maximum (minMaxLoc with the cell mask)
+    float m = -FLT_MAX;
+    for (int i = tid; i < cw * ch; i += 256) {
+        int yy = y0 + i / cw, xx = x0 + i % cw;
+        m = fmaxf(m, eig[(size_t)yy * w + xx]);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) s_red[wv] = m;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const double maxVal = m > 0 ? (double)m : 0.0;
+    const float thr = (float)(maxVal * quality);
+    // 2. candidates: above threshold (THRESH_TOZERO) and equal to the 3x3 dilation of the thresholded map
+    const int ya = max(y0, 1), yb = min(y1, h - 1), xa = max(x0, 1), xb = min(x1, w - 1);
+    const int cw2 = xb - xa, n_in = cw2 > 0 && yb > ya ? cw2 * (yb - ya) : 0;
+    for (int i = tid; i < n_in; i += 256) {
+        int yy = ya + i / cw2, xx = xa + i % cw2;
+        const float* p = eig + (size_t)yy * w + xx;
+        float v = p[0];
+        if (!(v > thr)) continue;
+        float mx = v;
+#pragma unroll
+        for (int j = -1; j <= 1; j++)
+#pragma unroll
+            for (int k = -1; k <= 1; k++) {
+                float q = p[j * w + k];
+                q = q > thr ? q : 0.f;
+                mx = fmaxf(mx, q);
+            }
+        if (v == mx) {
+            int slot = atomicAdd(&s_n, 1);
+            if (slot < GF_CAP) s_key[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx);
+        }
+    }
+    __syncthreads();
+    int n = s_n;
+    if (n > GF_CAP) {
+        if (tid == 0) atomicOr(&flags[0], 4);
+        n = GF_CAP;
+    }
+    // 3. sort descending by (value, address): bitonic network on the next power of two (padding keys = 0 sink to the end)
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = n + tid; i < np2; i += 256) s_key[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                int l = i ^ j;
+                if (l > i) {
+                    unsigned long long a = s_key[i], b = s_key[l];
+                    bool desc = (i & k) == 0;
+                    if (desc ? a < b : a > b) { s_key[i] = b; s_key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // 4. greedy minimum-distance pick by one wavefront (candidates in sorted order, accepted corners on the lanes)
+    if (wv == 0) {
+        const float md2 = (float)(min_dist * min_dist);
+        int nacc = 0;
+        const int lim = min(max_corners > 0 ? max_corners : GF_MAXCORNERS, GF_MAXCORNERS);
+        for (int i = 0; i < n && nacc < lim; i++) {
+            unsigned pos = (unsigned)(s_key[i] & 0xFFFFFFFFull);
+            int yy = pos / w, xx = pos - yy * w;
+            bool bad = false;
+            if (min_dist >= 1.0)
+                for (int jb = 0; jb < nacc; jb += 64) {
+                    int j = jb + lane;
+                    bool near = false;
+                    if (j < nacc) {
+                        float dx = (float)xx - s_ax[j], dy = (float)yy - s_ay[j];
+                        near = dx * dx + dy * dy < md2;
+                    }
+                    bad = bad || __any(near);
+                }
+            if (!bad) {
+                if (lane == 0) {
+                    s_ax[nacc] = (float)xx; s_ay[nacc] = (float)yy;
+                    out_xy[((size_t)cell * lim + nacc) * 2] = (float)xx;
+                    out_xy[((size_t)cell * lim + nacc) * 2 + 1] = (float)yy;
+                }
+                nacc++;
+            }
+        }
+        if (lane == 0) out_n[cell] = nacc;
+    }
+}
+
+int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, float* d_eig, float* d_xy, int* d_n) {
+    const int rows = 8, cols = 8, ch = h / rows, cw = w / cols, per_cell = n_features / (rows * cols);
+    if (per_cell > GF_MAXCORNERS) return mo_fail(c, MO_ERR_UNSUPPORTED, "more than 256 corners per grid cell");
+    hipLaunchKernelGGL(k_min_eigen, dim3((w + ME_TW - 1) / ME_TW, (h + ME_TH - 1) / ME_TH), dim3(256), 0, c->stream, d_gray, w, h, d_eig);
+    hipLaunchKernelGGL(k_gftt_cell, dim3(rows * cols), dim3(256), 0, c->stream, d_eig, w, h, cols, cw, ch, per_cell, 0.01, 10.0,
+                       d_xy, d_n, c->d_flags);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}

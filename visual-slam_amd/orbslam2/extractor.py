@@ -8,14 +8,14 @@ Reference behaviour mirrored per method (file:line of the reference):
   compute             extractor.py:68-83   orb.compute(image, keypoints); returns the ORIGINAL keypoint list next to the
                                            descriptors of the keypoints cv2 kept (the reference's index quirk is kept)
   extract_features    extractor.py:146-160 dispatch on `distributed`
-  distribute_keypoints extractor.py:85-144 grid Shi-Tomasi + compute: SURVEY.md 8f-1 ("next" row), not built yet
+  distribute_keypoints extractor.py:85-144 grid Shi-Tomasi (min-eigenvalue map once, one workgroup per cell) + compute
 """
 import os
 
 import numpy as np
 
 import vslam_amd
-from .types import keypoints_from_array, keypoints_to_array
+from .types import KeyPoint, keypoints_from_array, keypoints_to_array
 
 
 def _default_order():
@@ -69,9 +69,20 @@ class ORBExtractor:
         return keypoints, self.orb.compute(image, keypoints)[1]
 
     def distribute_keypoints(self, image, n_features=None):
-        raise NotImplementedError(
-            "distribute_keypoints (grid Shi-Tomasi, reference extractor.py:85-144) is the next row of the hot-path "
-            "scope table (SURVEY.md 8f-1) and is not built yet; call extract_features(image, distributed=False)")
+        """Grid-based detection (reference extractor.py:85-144): 8x8 cells, Shi-Tomasi corners per cell
+        (maxCorners = n_features // 64, qualityLevel 0.01, minDistance 10), KeyPoint(x, y, 31) each, then
+        orb.compute on all of them.  Like the reference, the returned list holds ALL corners while the descriptor
+        rows are those cv2 keeps (corners within 31 px of the border are dropped by compute)."""
+        if n_features is None:
+            n_features = self.n_features
+        image = np.asarray(image)
+        xy = vslam_amd.default_context().grid_good_features(image, n_features)
+        all_keypoints = [KeyPoint(float(x), float(y), 31) for x, y in xy]
+        if all_keypoints:
+            _, descriptors = self.orb.compute(image, all_keypoints)
+        else:
+            descriptors = None
+        return all_keypoints, descriptors
 
     def extract_features(self, image, distributed=True):
         if distributed:

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mo_device_count": (_i, []),
     "mo_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mo_orb_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "mo_orb_grid_good_features": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mo_dbg_min_eigen": (_i, [_vp, _vp, _i, _i, _vp]),
     "mo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "mo_init_two_view": (_i, [_vp, _vp, _vp, _i, _vp, _d, _d, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mo_triangulate_points": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -186,6 +188,23 @@ class Context:
         self._check(self.lib.mo_orb_compute(self.h, C.byref(prm), _ptr(a), w, h, w * ch, ch, _ptr(k), n, _ptr(kept),
                                             _ptr(desc), C.byref(n_out)))
         return kept[:n_out.value].copy(), desc[:n_out.value].copy()
+
+    def grid_good_features(self, image, n_features):
+        """corner stage of ORBExtractor.distribute_keypoints -> (N,2) float32 (x, y), cell-major order"""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        ch = 3 if a.ndim == 3 else 1
+        h, w = a.shape[0], a.shape[1]
+        xy = np.zeros((64 * max(int(n_features) // 64, 1), 2), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.mo_orb_grid_good_features(self.h, _ptr(a), w, h, w * ch, ch, int(n_features), _ptr(xy), C.byref(n)))
+        return xy[:n.value].copy()
+
+    def dbg_min_eigen(self, gray):
+        g = np.ascontiguousarray(gray, np.uint8)
+        h, w = g.shape
+        out = np.zeros((h, w), np.float32)
+        self._check(self.lib.mo_dbg_min_eigen(self.h, _ptr(g), w, h, _ptr(out)))
+        return out
 
     def match_knn2_ratio(self, q, t, ratio=None):
         """q (nq,32) or (B,nq,32), t likewise -> idx (..,nq,2) i32, dist (..,nq,2) i32, pass (..,nq) bool"""
