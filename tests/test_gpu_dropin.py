@@ -198,7 +198,8 @@ def test_tracker_call_sequence():
     initializer.set_first_frame(kp0, d0, frames[0])                                # tracker.py:162
     kp1, d1 = extractor.extract_features(frames[1], distributed=False)
     ok, R, t, pts, matches = initializer.initialize(kp1, d1, matcher, frames[1])   # tracker.py:168-170
-    assert isinstance(ok, bool) and len(matches) > 300
+    assert isinstance(ok, bool) and len(matcher.match(d0, d1)) > 300   # (a pure pan is planar-degenerate: `matches`
+    # returned by initialize are the cheirality survivors, possibly few)
     if ok:
         assert R.shape == (3, 3) and t.shape == (3, 1) and abs(np.linalg.det(R) - 1) < 1e-9
         assert abs(np.linalg.norm(t) - 1) < 1e-9 and len(pts) == len(matches)

@@ -58,3 +58,22 @@ def test_batched(ctx):
     for b in range(3):
         i1, d1, p1 = ctx.match_knn2_ratio(q[b], t[b], 0.8)
         assert np.array_equal(idx[b], i1) and np.array_equal(dist[b], d1) and np.array_equal(ps[b], p1)
+
+
+def test_property_random_shapes_and_ties(ctx):
+    """hypothesis: random sizes incl. nt in {1, 2}, heavy duplicates -> (idx, dist, pass) equal the oracle bit for bit."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 300), st.integers(1, 300), st.integers(1, 8), st.sampled_from([0.6, 0.75, 0.85, 1.0]),
+           st.integers(0, 2 ** 31 - 1))
+    def run(nq, nt, pool, ratio, seed):
+        rng = np.random.default_rng(seed)
+        words = rng.integers(0, 256, (pool, 32), dtype=np.uint8)       # few distinct descriptors -> many exact ties
+        q = words[rng.integers(0, pool, nq)].copy()
+        t = words[rng.integers(0, pool, nt)].copy()
+        flip = rng.random(nq) < 0.5
+        q[flip, rng.integers(0, 32)] ^= np.uint8(1 << rng.integers(0, 8))
+        _check(ctx, q, t, ratio)
+
+    run()

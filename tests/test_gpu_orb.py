@@ -161,3 +161,51 @@ def test_no_keypoints_on_flat_image(ctx):
     p = V.orb_params()
     (kps, desc), = ctx.orb_detect_compute(np.full((480, 640), 128, np.uint8), p)
     assert len(kps) == 0 and desc is None
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_full_hd_frame_uses_hbm_scratch_path(order, O):
+    """1920x1080: level 0 has far more candidates than the 48 KB LDS window -> the selection replay runs out of its
+    HBM scratch slot (and, at threshold 3, past the 65535-element wave-partition limit)."""
+    import vslam_amd as V
+    ctx = V.Context(device=0, max_w=1920, max_h=1080, max_batch=1)
+    img = synthetic_frame(77, 1920, 1080)
+    O.lib().orc_set_variant(order, 0)
+    for nfeat, thr in ((2000, 7), (5000, 3)):
+        p, o = _prm(V, O, order, nfeatures=nfeat, fast_threshold=thr)
+        (kps, desc), = ctx.orb_detect_compute(img, p)
+        ek, ed = O.detect_and_compute(img, o)
+        assert len(kps) == len(ek)
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(kps[f], ek[f]), f
+        assert np.array_equal(desc, ed)
+    O.lib().orc_set_variant(1, 0)
+    ctx.close()
+
+
+def test_small_and_odd_sizes(ctx, O):
+    import vslam_amd as V
+    for (w, h), nlev in (((97, 131), 3), ((64, 64), 1), ((641, 479), 8), ((200, 150), 8)):
+        img = synthetic_frame(9, w, h)
+        p, o = _prm(V, O, V.ORDER_LIBSTDCXX, nfeatures=300, nlevels=nlev)
+        O.lib().orc_set_variant(0, 0)
+        (kps, desc), = ctx.orb_detect_compute(img, p)
+        ek, ed = O.detect_and_compute(img, o)
+        assert np.array_equal(kps, ek.astype(kps.dtype)) or all(np.array_equal(kps[f], ek[f]) for f in kps.dtype.names)
+        if len(ek):
+            assert np.array_equal(desc, ed)
+        else:
+            assert desc is None
+    O.lib().orc_set_variant(1, 0)
+
+
+def test_bad_arguments_fail_loudly(ctx):
+    import vslam_amd as V
+    with pytest.raises(V.NativeError):
+        ctx.orb_detect_compute(np.zeros((32, 32), np.uint8), V.orb_params())          # below 64x64
+    with pytest.raises(V.NativeError):
+        ctx.orb_detect_compute(np.zeros((2000, 2000), np.uint8), V.orb_params())      # above the context's max size
+    bad = V.orb_params()
+    bad.wta_k = 3
+    with pytest.raises(V.NativeError):
+        ctx.orb_detect_compute(np.zeros((480, 640), np.uint8), bad)
