@@ -280,6 +280,7 @@ __device__ __forceinline__ int arc_score(const int d[16]) {
 //     work is dealt to the 4 wavefronts in (row, 64-column) units
 //  3. 3x3 non-max suppression + border filter + raster-ordered compaction: each thread owns a contiguous run of
 //     the row-major strip, a block scan of the per-thread popcounts gives the output slot
+template <int TW>  // LDS tile pitch: a compile-time constant so the 16 circle reads use immediate offsets
 __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -303,9 +304,9 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
 
     // ---- 1. stage pixels: rows y0-4 .. y0+rows+3, columns gx0 .. gx0+TW (gx0 = (xs0-3) rounded down to 4)
     const int gx0 = (xs0 - 3) & ~3, lead = xs0 - 3 - gx0;
-    const int TW = (SW + 6 + lead + 3) & ~3, th = rows + 8, gy0 = y0 - 4;
+    const int tw_used = (SW + 6 + lead + 3) & ~3, th = rows + 8, gy0 = y0 - 4;
     if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {
-        const int tw4 = TW >> 2;
+        const int tw4 = tw_used >> 2;
         for (int r = wv; r < th; r += 4) {
             const uint32_t* src = (const uint32_t*)(img + (size_t)(gy0 + r) * lv.pitch + gx0);
             uint32_t* dst = (uint32_t*)(s_tile + r * TW);
@@ -314,12 +315,15 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     } else {
         for (int r = wv; r < th; r += 4) {
             const uint8_t* src = img + (size_t)(gy0 + r) * lv.pitch + gx0;
-            for (int cc = lane; cc < TW; cc += 64) s_tile[r * TW + cc] = (gx0 + cc < lv.w) ? src[cc] : 0;
+            for (int cc = lane; cc < tw_used; cc += 64) s_tile[r * TW + cc] = (gx0 + cc < lv.w) ? src[cc] : 0;
         }
     }
     __syncthreads();
 
-    // ---- 2. scores (queueing the corners in LDS and scoring them densely was measured: no gain, lower occupancy)
+    // ---- 2. scores.  With lo = max over the 16 arcs of min(d over the 9-arc) and hi = min over arcs of max(d over arc):
+    // dark corner <=> lo > t, bright corner <=> -hi > t, and cornerScore = max(t, lo, -hi) - 1.  Two 3-input min/max
+    // networks (m3[i] = op(d[i..i+2]), m9[i] = op(m3[i], m3[i+3], m3[i+6])) give test and score at once: no bit masks,
+    // no divergent second pass.
     const int nxc = (SW + 63) >> 6;
     {
         int r = 0, j = wv;
@@ -331,22 +335,20 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
                 const int v = p[0];
                 int d[16];
                 FAST_LOAD_D(d, v, p, TW)
-                uint32_t md = 0, mb = 0;
+                int mn3[16], mx3[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    md |= (d[k] > t ? 1u : 0u) << k;
-                    mb |= (d[k] < -t ? 1u : 0u) << k;
+                for (int i = 0; i < 16; i++) {
+                    mn3[i] = min(d[i], min(d[(i + 1) & 15], d[(i + 2) & 15]));
+                    mx3[i] = max(d[i], max(d[(i + 1) & 15], d[(i + 2) & 15]));
                 }
-                int sc = 0;
-                const bool dark = arc9(md), bright = arc9(mb);
-                if (dark || bright) {
-                    if (bright) {
+                int lo = -512, hi = 512;
 #pragma unroll
-                        for (int k = 0; k < 16; k++) d[k] = -d[k];
-                    }
-                    sc = arc_score(d);
+                for (int i = 0; i < 16; i++) {
+                    lo = max(lo, min(mn3[i], min(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
+                    hi = min(hi, max(mx3[i], max(mx3[(i + 3) & 15], mx3[(i + 6) & 15])));
                 }
-                s_score[r * SW + x] = (uint8_t)sc;
+                const int best = max(lo, -hi);
+                s_score[r * SW + x] = (uint8_t)(best > t ? best - 1 : 0);
             }
             j += 4;
             while (j >= nxc) { j -= nxc; r++; }
@@ -396,26 +398,36 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     if (tid == 0) strip_cnt[(size_t)frame * P.strips_per_frame + lv.strip_base + strip] = min(total, lv.strip_cap);
 }
 
-int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
+template <int TW> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, int batch, size_t score_bytes, int max_rows) {
     const Plan& P = c->plan;
-    size_t score_bytes = 0, tile_bytes = 0;
-    for (int L = 0; L < P.nlevels; L++) {
-        const LevelInfo& v = P.lv[L];
-        score_bytes = std::max(score_bytes, (((size_t)(v.strip_rows + 2) * (v.bw + 2) + 15) & ~(size_t)15));
-        tile_bytes = std::max(tile_bytes, (size_t)(v.strip_rows + 8) * ((v.bw + 2 + 6 + 3 + 3) & ~3));
-    }
-    size_t lds = score_bytes + tile_bytes + 16;
+    size_t lds = score_bytes + (size_t)(max_rows + 8) * TW + 16;
     if (lds > 128 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
-    if (P.strips_per_frame < 1) return MO_OK;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_fast, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+    hipLaunchKernelGGL(k_fast<TW>, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr, c->d_cand,
                        c->d_strip_cnt, (int)score_bytes);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
+}
+
+int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
+    const Plan& P = c->plan;
+    size_t score_bytes = 0;
+    int tw_need = 0, max_rows = 1;
+    for (int L = 0; L < P.nlevels; L++) {
+        const LevelInfo& v = P.lv[L];
+        score_bytes = std::max(score_bytes, (((size_t)(v.strip_rows + 2) * (v.bw + 2) + 15) & ~(size_t)15));
+        tw_need = std::max(tw_need, (v.bw + 2 + 6 + 3 + 3) & ~3);
+        max_rows = std::max(max_rows, v.strip_rows);
+    }
+    if (P.strips_per_frame < 1) return MO_OK;
+    if (tw_need <= 704) return launch_fast_tw<704>(c, d_gray, batch, score_bytes, max_rows);
+    if (tw_need <= 1344) return launch_fast_tw<1344>(c, d_gray, batch, score_bytes, max_rows);
+    if (tw_need <= 2112) return launch_fast_tw<2112>(c, d_gray, batch, score_bytes, max_rows);
+    return launch_fast_tw<4160>(c, d_gray, batch, score_bytes, max_rows);
 }
 
 // ------------------------------------------------------------------ select --------------------------
@@ -617,7 +629,9 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
                                             int cx, int cy, float angle_deg, uint8_t* desc, int lane) {
     float angle = angle_deg;
     angle *= (float)(3.14159265358979323846 / 180.f);
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    double sd, cd;
+    sincos((double)angle, &sd, &cd);  // f64 then rounded to f32, as cv2's (float)cos(angle) / (float)sin(angle)
+    float a = (float)cd, b = (float)sd;
     unsigned nib = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -649,11 +663,11 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
 // stage a rows x ndw-dword window whose first column is x0 (rounded down to 4) into a wavefront-private LDS patch
 __device__ __forceinline__ void stage_patch(const uint8_t* img, int pitch, int x0a, int y0, int rows, int ndw, uint8_t* dst,
                                             int dpitch, int lane, bool aligned) {
-    if (aligned) {
-        for (int i = lane; i < rows * ndw; i += 64) {
-            int r = i / ndw, c4 = i - r * ndw;
-            *(uint32_t*)(dst + r * dpitch + 4 * c4) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * c4);
-        }
+    if (aligned) {  // 16 lanes per row (ndw <= 11 of them active), 4 rows per trip
+        const int c4 = lane & 15;
+        if (c4 < ndw)
+            for (int r = lane >> 4; r < rows; r += 4)
+                *(uint32_t*)(dst + r * dpitch + 4 * c4) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * c4);
     } else {
         for (int i = lane; i < rows * ndw * 4; i += 64) {
             int r = i / (ndw * 4), cidx = i - r * (ndw * 4);
