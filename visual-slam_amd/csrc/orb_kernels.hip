@@ -660,33 +660,65 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
 #define DP_BLR_PITCH 44   // 39 columns + <= 3 alignment lead-in, 11 dwords
 #define DP_WAVE_BYTES (31 * DP_RAW_PITCH + 39 * DP_BLR_PITCH)
 
-// stage a rows x ndw-dword window whose first column is x0 (rounded down to 4) into a wavefront-private LDS patch
+// stage a rows x ndw-dword window whose first column is x0a (a multiple of 4) into a half-wave-private LDS patch;
+// hl = lane within the 32-lane half: 16 lanes per row (ndw <= 11 active), 2 rows per trip
 __device__ __forceinline__ void stage_patch(const uint8_t* img, int pitch, int x0a, int y0, int rows, int ndw, uint8_t* dst,
-                                            int dpitch, int lane, bool aligned) {
-    if (aligned) {  // 16 lanes per row (ndw <= 11 of them active), 4 rows per trip
-        const int c4 = lane & 15;
+                                            int dpitch, int hl, bool aligned) {
+    if (aligned) {
+        const int c4 = hl & 15;
         if (c4 < ndw)
-            for (int r = lane >> 4; r < rows; r += 4)
+            for (int r = hl >> 4; r < rows; r += 2)
                 *(uint32_t*)(dst + r * dpitch + 4 * c4) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * c4);
     } else {
-        for (int i = lane; i < rows * ndw * 4; i += 64) {
+        for (int i = hl; i < rows * ndw * 4; i += 32) {
             int r = i / (ndw * 4), cidx = i - r * (ndw * 4);
             dst[r * dpitch + cidx] = (x0a + cidx < pitch) ? img[(size_t)(y0 + r) * pitch + x0a + cidx] : 0;
         }
     }
 }
 
-// One wavefront per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred patch (rBRIEF) are
-// staged in LDS with aligned dword loads; the orientation sums and the 256 rotated tests then read LDS only.
+__device__ __forceinline__ int half_sum(int v) {  // sum over the 32 lanes of a half-wavefront
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 256 rotated binary tests from an LDS patch, 8 per lane of a half-wavefront: lane hl produces descriptor byte hl
+__device__ __forceinline__ uint8_t rbrief_byte(const uint8_t* patch, int ppitch, int cx, int cy, float angle_deg, int hl) {
+    float angle = angle_deg;
+    angle *= (float)(3.14159265358979323846 / 180.f);
+    double sd, cd;
+    sincos((double)angle, &sd, &cd);  // f64 then rounded to f32, as cv2's (float)cos(angle) / (float)sin(angle)
+    const float a = (float)cd, b = (float)sd;
+    unsigned val = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int8_t* pt = &c_pattern[(hl * 8 + k) * 4];
+        float fx0 = (float)pt[0], fy0 = (float)pt[1], fx1 = (float)pt[2], fy1 = (float)pt[3];
+        int ix0 = __float2int_rn(fx0 * a - fy0 * b), iy0 = __float2int_rn(fx0 * b + fy0 * a);
+        int ix1 = __float2int_rn(fx1 * a - fy1 * b), iy1 = __float2int_rn(fx1 * b + fy1 * a);
+        int t0 = patch[(cy + iy0) * ppitch + cx + ix0];
+        int t1 = patch[(cy + iy1) * ppitch + cx + ix1];
+        val |= (t0 < t1 ? 1u : 0u) << k;
+    }
+    return (uint8_t)val;
+}
+
+#define DK_PER_WG 8  // keypoints per 256-thread workgroup: one per half-wavefront
+
+// One HALF-wavefront (32 lanes) per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred patch
+// (rBRIEF) are staged in LDS with aligned dword loads; orientation sums and the 256 rotated tests then read LDS only.
+// Pairing two keypoints per wavefront shares the instruction stream of the per-keypoint scalar work (level lookup,
+// fastAtan2, the f64 sincos) between them.
 __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                                   const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
                                                   int* flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[4 * DP_WAVE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_WAVE_BYTES];
     const int frame = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int k = blockIdx.x * 4 + wv;
+    const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
+    const int k = blockIdx.x * DK_PER_WG + half;
     const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
     int total = 0, L = -1, idx = 0;
     for (int l = 0; l < P.nlevels; l++) {
@@ -694,15 +726,15 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         if (L < 0 && k < total + n) { L = l; idx = k - total; }
         total += n;
     }
-    if (k == 0 && lane == 0) {
+    if (k == 0 && hl == 0) {
         counts[frame] = total;
         if (total > cap) atomicOr(&flags[0], 2);
     }
-    const bool active = L >= 0 && k < cap;  // wave-uniform
-    uint8_t* s_raw = s_patch + wv * DP_WAVE_BYTES;
+    const bool active = L >= 0 && k < cap;  // uniform within the half-wavefront
+    uint8_t* s_raw = s_patch + half * DP_WAVE_BYTES;
     uint8_t* s_blr = s_raw + 31 * DP_RAW_PITCH;
     const LevelInfo lv = P.lv[active ? L : 0];
-    int x = 0, y = 0, offr = 0, offb = 0, cx = 0, cy = 0;
+    int x = 0, y = 0, offr = 0, offb = 0;
     float response = 0.f, px = 0.f, py = 0.f;
     if (active) {
         FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
@@ -712,24 +744,23 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         const int xr0 = (x - 15) & ~3;
         offr = (x - 15) - xr0;
         const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
-        stage_patch(img, lv.pitch, xr0, y - 15, 31, min(9, (lv.pitch - xr0) >> 2), s_raw, DP_RAW_PITCH, lane, al_raw);
+        stage_patch(img, lv.pitch, xr0, y - 15, 31, min(9, (lv.pitch - xr0) >> 2), s_raw, DP_RAW_PITCH, hl, al_raw);
         if (desc) {
             float inv = 1.f / lv.scale;
-            cx = __float2int_rn(px * inv); cy = __float2int_rn(py * inv);
+            int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
             const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
             const int xb0 = (cx - 19) & ~3;
             offb = (cx - 19) - xb0;
-            stage_patch(bl, lv.bpitch, xb0, cy - 19, 39, min(11, (lv.bpitch - xb0) >> 2), s_blr, DP_BLR_PITCH, lane, true);
+            stage_patch(bl, lv.bpitch, xb0, cy - 19, 39, min(11, (lv.bpitch - xb0) >> 2), s_blr, DP_BLR_PITCH, hl, true);
         }
     }
     __syncthreads();
-    if (!active) return;
-    // intensity centroid over the radius-15 disc: one row per lane
+    // intensity centroid over the radius-15 disc: one row per lane (31 of the 32 lanes)
     int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        int v = lane - 15;
+    if (active && hl < 31) {
+        int v = hl - 15;
         int d = P.umax[v < 0 ? -v : v];
-        const uint8_t* row = s_raw + lane * DP_RAW_PITCH + 15 + offr;
+        const uint8_t* row = s_raw + hl * DP_RAW_PITCH + 15 + offr;
         int rs = 0;
         for (int u = -d; u <= d; u++) {
             int p = row[u];
@@ -738,11 +769,12 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         }
         m01 = v * rs;
     }
-    m10 = wave_sum(m10);
-    m01 = wave_sum(m01);
+    m10 = half_sum(m10);
+    m01 = half_sum(m01);
+    if (!active) return;
     float angle = fast_atan2_deg((float)m01, (float)m10);
     mo_keypoint* o = kps + (size_t)frame * cap + k;
-    if (lane == 0) {
+    if (hl == 0) {
         o->x = px; o->y = py;
         o->size = 31 * lv.scale;
         o->angle = angle;
@@ -750,18 +782,14 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         o->octave = L;
         o->class_id = -1;
     }
-    if (desc) {
-        // patch-local coordinates: centre (19 + offb, 19) inside the staged window; bounds are guaranteed by
-        // edge_threshold >= 19 + pattern radius <= 18
-        rbrief_wave<false>(s_blr, DP_BLR_PITCH, s_blr, DP_BLR_PITCH, 0, 0, 19 + offb, 19, angle,
-                           desc + ((size_t)frame * cap + k) * 32, lane);
-    }
+    if (desc)  // patch-local centre (19 + offb, 19); bounds guaranteed by edge_threshold >= 19 and pattern radius <= 18
+        desc[((size_t)frame * cap + k) * 32 + hl] = rbrief_byte(s_blr, DP_BLR_PITCH, 19 + offb, 19, angle, hl);
 }
 
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
                         int* d_counts) {
     const Plan& P = c->plan;
-    hipLaunchKernelGGL(k_describe, dim3((cap + 3) / 4, batch), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur,
+    hipLaunchKernelGGL(k_describe, dim3((cap + DK_PER_WG - 1) / DK_PER_WG, batch), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur,
                        c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->d_flags);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
