@@ -470,7 +470,7 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
 
 // phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota), write-out
 template <class PA, class PB>
-__device__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1, uint16_t* rpos,
+__device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1, uint16_t* rpos,
                               unsigned long long* bl, FinalKp* fin, int* fin_cnt_out, int* flags) {
     const int lane = threadIdx.x;
     for (int i = lane; i < N1; i += WAVE) {

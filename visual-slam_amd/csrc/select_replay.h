@@ -37,7 +37,7 @@ template <class P> __device__ __forceinline__ void swp(P a, int i, int j) {
 }
 
 // ---------------------------------------------------------------- libstdc++ ------------------------
-template <class T, class P> __device__ void ls_move_median_to_first(P a, int result, int ia, int ib, int ic) {
+template <class T, class P> __device__ __forceinline__ void ls_move_median_to_first(P a, int result, int ia, int ib, int ic) {
     typedef Rec<T> R;
     if (R::gt(a[ia], a[ib])) {
         if (R::gt(a[ib], a[ic])) swp(a, result, ib);
@@ -48,7 +48,7 @@ template <class T, class P> __device__ void ls_move_median_to_first(P a, int res
     else swp(a, result, ib);
 }
 
-template <class T, class P> __device__ int ls_unguarded_partition(P a, int first, int last, int pivot) {
+template <class T, class P> __device__ __forceinline__ int ls_unguarded_partition(P a, int first, int last, int pivot) {
     typedef Rec<T> R;
     const T pv = a[pivot];
     while (true) {
@@ -61,7 +61,7 @@ template <class T, class P> __device__ int ls_unguarded_partition(P a, int first
     }
 }
 
-template <class T, class P> __device__ void ls_push_heap(P a, int first, int hole, int top, T value) {
+template <class T, class P> __device__ __forceinline__ void ls_push_heap(P a, int first, int hole, int top, T value) {
     typedef Rec<T> R;
     int parent = (hole - 1) / 2;
     while (hole > top && R::gt(a[first + parent], value)) {
@@ -72,7 +72,7 @@ template <class T, class P> __device__ void ls_push_heap(P a, int first, int hol
     a[first + hole] = value;
 }
 
-template <class T, class P> __device__ void ls_adjust_heap(P a, int first, int hole, int len, T value) {
+template <class T, class P> __device__ __forceinline__ void ls_adjust_heap(P a, int first, int hole, int len, T value) {
     typedef Rec<T> R;
     const int top = hole;
     int second = hole;
@@ -90,7 +90,7 @@ template <class T, class P> __device__ void ls_adjust_heap(P a, int first, int h
     ls_push_heap<T>(a, first, hole, top, value);
 }
 
-template <class T, class P> __device__ void ls_heap_select(P a, int first, int middle, int last) {
+template <class T, class P> __device__ __forceinline__ void ls_heap_select(P a, int first, int middle, int last) {
     typedef Rec<T> R;
     // __make_heap(first, middle)
     int len = middle - first;
@@ -113,7 +113,7 @@ template <class T, class P> __device__ void ls_heap_select(P a, int first, int m
     }
 }
 
-template <class T, class P> __device__ void ls_insertion_sort(P a, int first, int last) {
+template <class T, class P> __device__ __forceinline__ void ls_insertion_sort(P a, int first, int last) {
     typedef Rec<T> R;
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
@@ -133,7 +133,7 @@ template <class T, class P> __device__ void ls_insertion_sort(P a, int first, in
     }
 }
 
-template <class T, class P> __device__ void ls_introselect(P a, int first, int nth, int last, int depth) {
+template <class T, class P> __device__ __forceinline__ void ls_introselect(P a, int first, int nth, int last, int depth) {
     while (last - first > 3) {
         if (depth == 0) {
             ls_heap_select<T>(a, first, nth + 1, last);
@@ -150,13 +150,13 @@ template <class T, class P> __device__ void ls_introselect(P a, int first, int n
     ls_insertion_sort<T>(a, first, last);
 }
 
-template <class T, class P> __device__ void ls_nth_element(P a, int first, int nth, int last) {
+template <class T, class P> __device__ __forceinline__ void ls_nth_element(P a, int first, int nth, int last) {
     if (first == last || nth == last) return;
     ls_introselect<T>(a, first, nth, last, (31 - __clz(last - first)) * 2);
 }
 
 // ---------------------------------------------------------------- MSVC STL -------------------------
-template <class T, class P> __device__ void ms_med3(P a, int first, int mid, int last) {
+template <class T, class P> __device__ __forceinline__ void ms_med3(P a, int first, int mid, int last) {
     typedef Rec<T> R;
     if (R::gt(a[mid], a[first])) swp(a, mid, first);
     if (R::gt(a[last], a[mid])) {
@@ -165,7 +165,7 @@ template <class T, class P> __device__ void ms_med3(P a, int first, int mid, int
     }
 }
 
-template <class T, class P> __device__ void ms_guess_median(P a, int first, int mid, int last) {  // last inclusive
+template <class T, class P> __device__ __forceinline__ void ms_guess_median(P a, int first, int mid, int last) {  // last inclusive
     const int count = last - first;
     if (40 < count) {
         const int step = (count + 1) >> 3;
@@ -179,7 +179,7 @@ template <class T, class P> __device__ void ms_guess_median(P a, int first, int 
     }
 }
 
-template <class T, class P> __device__ void ms_partition(P a, int first, int last, int& out_first, int& out_last) {
+template <class T, class P> __device__ __forceinline__ void ms_partition(P a, int first, int last, int& out_first, int& out_last) {
     typedef Rec<T> R;
     int mid = first + ((last - first) >> 1);
     ms_guess_median<T>(a, first, mid, last - 1);
@@ -218,7 +218,7 @@ template <class T, class P> __device__ void ms_partition(P a, int first, int las
     }
 }
 
-template <class T, class P> __device__ void ms_insertion_sort(P a, int first, int last) {
+template <class T, class P> __device__ __forceinline__ void ms_insertion_sort(P a, int first, int last) {
     typedef Rec<T> R;
     if (first == last) return;
     for (int mid = first + 1; mid != last; ++mid) {
@@ -239,7 +239,7 @@ template <class T, class P> __device__ void ms_insertion_sort(P a, int first, in
     }
 }
 
-template <class T, class P> __device__ void ms_nth_element(P a, int first, int nth, int last) {
+template <class T, class P> __device__ __forceinline__ void ms_nth_element(P a, int first, int nth, int last) {
     if (nth == last) return;
     while (32 < last - first) {
         int mf, ml;
@@ -253,7 +253,7 @@ template <class T, class P> __device__ void ms_nth_element(P a, int first, int n
 
 // std::partition (bidirectional form, same permutation in libstdc++ and the MSVC STL):
 // elements with response >= thr first.  Returns the number of elements satisfying the predicate.
-template <class T, class P> __device__ int partition_ge(P a, int first, int last, T thr) {
+template <class T, class P> __device__ __forceinline__ int partition_ge(P a, int first, int last, T thr) {
     typedef Rec<T> R;
     const int begin = first;
     while (true) {
@@ -274,7 +274,7 @@ template <class T, class P> __device__ int partition_ge(P a, int first, int last
 }
 
 // KeyPointsFilter::retainBest on records a[0..n): returns the surviving count, survivors in a[0..ret)
-template <class T, class P> __device__ int retain_best(P a, int n, int n_points, int order) {
+template <class T, class P> __device__ __forceinline__ int retain_best(P a, int n, int n_points, int order) {
     if (n_points < 0 || n <= n_points) return n;
     if (n_points == 0) return 0;
     if (order == MO_ORDER_MSVC) ms_nth_element<T>(a, 0, n_points - 1, n);
@@ -293,7 +293,7 @@ template <class T, class P> __device__ int retain_best(P a, int n, int n_points,
 //   L_k = k-th position from the left with !(a > pivot),  R_k = k-th from the right with !(pivot > a)
 //   K   = #{k : L_k < R_k};  swap a[L_k] <-> a[R_k] for k <= K;  cut = min(L_{K+1}, R_K)
 // All 64 lanes call these functions convergently (block = one wavefront).  rpos: u16[>= n/2], bl: u64[>= n/64 + 1].
-#define REPLAY_SERIAL_BELOW 160  // ranges this short are finished by one lane (three wave passes cost more)
+#define REPLAY_SERIAL_BELOW 12  // ranges this short are finished by one lane (a wave partition step costs ~1.5k cycles)
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -303,7 +303,7 @@ __device__ __forceinline__ int wave_min_i(int v) {
 
 // generic pairing partition: stopL(v) / stopR(v) classify an element; returns cut (absolute index) and total of R
 template <class T, class P, class FL, class FR>
-__device__ int wave_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
+__device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
                                    int lane, int* total_r) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     int TR = 0;
@@ -352,7 +352,7 @@ __device__ int wave_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint
 }
 
 template <class T, class P>
-__device__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int lane) {
+__device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int lane) {
     typedef Rec<T> R;
     if (first == last || nth == last) return;
     int depth = (31 - __clz(last - first)) * 2;
@@ -380,7 +380,7 @@ __device__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t*
 // retainBest, all lanes convergent.  libstdc++ order runs wave-parallel; the MSVC STL's three-way partition is
 // replayed by one lane.
 template <class T, class P>
-__device__ int wave_retain_best(P a, int n, int n_points, int order, uint16_t* rpos, unsigned long long* bl, int lane) {
+__device__ __forceinline__ int wave_retain_best(P a, int n, int n_points, int order, uint16_t* rpos, unsigned long long* bl, int lane) {
     typedef Rec<T> R;
     if (n_points < 0 || n <= n_points) return n;
     if (n_points == 0) return 0;
