@@ -468,24 +468,33 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
     return (((size_t)n * rec_bytes + 7) & ~(size_t)7) + ((((size_t)n / 2 + 1) * 2 + 7) & ~(size_t)7) + ((size_t)n / 64 + 2) * 8;
 }
 
-// phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota), write-out
+#define SEL_THREADS 256
+
+// phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order, all 4 wavefronts), retainBest(quota)
+// replayed by wavefront 0, write-out by all
 template <class PA, class PB>
-__device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1, uint16_t* rpos,
-                              unsigned long long* bl, FinalKp* fin, int* fin_cnt_out, int* flags) {
-    const int lane = threadIdx.x;
-    for (int i = lane; i < N1; i += WAVE) {
+__device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1,
+                                              uint16_t* rpos, unsigned long long* bl, FinalKp* fin, int* fin_cnt_out,
+                                              int* flags, int* s_n) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N1; i += SEL_THREADS) {
         uint32_t e = A[i];
         int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
         float r = harris_response(img, lv.pitch, x, y);
         B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
     }
     __syncthreads();
-    int N2 = replay::wave_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, lane);
+    if (tid < WAVE) {
+        int n2 = replay::wave_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid);
+        if (tid == 0) s_n[1] = n2;
+    }
+    __syncthreads();
+    int N2 = s_n[1];
     if (N2 > lv.fin_cap) {
-        if (lane == 0) atomicOr(&flags[0], 1);
+        if (tid == 0) atomicOr(&flags[0], 1);
         N2 = lv.fin_cap;
     }
-    for (int i = lane; i < N2; i += WAVE) {
+    for (int i = tid; i < N2; i += SEL_THREADS) {
         uint64_t e = B[i];
         FinalKp k;
         k.x = (uint16_t)(e & 0xFFF);
@@ -493,26 +502,29 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
         k.response = __uint_as_float((uint32_t)(e >> 32));
         fin[i] = k;
     }
-    if (lane == 0) *fin_cnt_out = N2;
+    if (tid == 0) *fin_cnt_out = N2;
 }
 
-__global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
-                                               const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
-                                               uint64_t* __restrict__ scratch, size_t scratch_stride,
-                                               FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags) {
+// One workgroup (4 wavefronts) per (frame, level).  Gather, Harris and write-out use all wavefronts; the two
+// retainBest replays run on wavefront 0 (wave-parallel pairing partition, select_replay.h).
+__global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                                        const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
+                                                        uint64_t* __restrict__ scratch, size_t scratch_stride,
+                                                        FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // SEL_BUF_BYTES
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
-    const int L = blockIdx.x, frame = blockIdx.y, lane = threadIdx.x;
+    __shared__ int s_n[2];
+    const int L = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
     if (lv.nstrips == 0) {
-        if (lane == 0) *fin_cnt_out = 0;
+        if (tid == 0) *fin_cnt_out = 0;
         return;
     }
     const int* cnts = strip_cnt + (size_t)frame * P.strips_per_frame + lv.strip_base;
-    for (int s = lane; s < lv.nstrips; s += WAVE) s_pref[s + 1] = cnts[s];
+    for (int s = tid; s < lv.nstrips; s += SEL_THREADS) s_pref[s + 1] = cnts[s];
     __syncthreads();
-    if (lane == 0) {
+    if (tid == 0) {
         s_pref[0] = 0;
         for (int s = 0; s < lv.nstrips; s++) s_pref[s + 1] += s_pref[s];
     }
@@ -528,19 +540,27 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
     uint32_t* s_A = (uint32_t*)s_buf;
     uint16_t* a_rpos = (uint16_t*)(s_buf + (((size_t)N * 4 + 7) & ~(size_t)7));
     unsigned long long* a_bl = (unsigned long long*)((uint8_t*)a_rpos + ((((size_t)N / 2 + 1) * 2 + 7) & ~(size_t)7));
+    // gather the strip lists in raster order: one wavefront per strip, strips dealt round-robin to the 4 wavefronts
     const uint32_t* src = cand + (size_t)frame * P.cand_stride + lv.cand_off;
-    for (int s = 0; s < lv.nstrips; s++) {
-        int b = s_pref[s], n = s_pref[s + 1] - b;
-        const uint32_t* e = src + (size_t)s * lv.strip_cap;
-        if (a_lds) for (int i = lane; i < n; i += WAVE) s_A[b + i] = e[i];
-        else for (int i = lane; i < n; i += WAVE) gA[b + i] = e[i];
+    {
+        const int lane = tid & 63;
+        for (int s = tid >> 6; s < lv.nstrips; s += SEL_THREADS / 64) {
+            int b = s_pref[s], n = s_pref[s + 1] - b;
+            const uint32_t* e = src + (size_t)s * lv.strip_cap;
+            if (a_lds) for (int i = lane; i < n; i += WAVE) s_A[b + i] = e[i];
+            else for (int i = lane; i < n; i += WAVE) gA[b + i] = e[i];
+        }
     }
     __syncthreads();
-    // pass 1: retainBest(2 * quota) on the FAST score
-    int N1;
-    if (a_lds) N1 = replay::wave_retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, lane);
-    else N1 = replay::wave_retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, lane);
+    // pass 1: retainBest(2 * quota) on the FAST score (wavefront 0)
+    if (tid < WAVE) {
+        int n1;
+        if (a_lds) n1 = replay::wave_retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, tid);
+        else n1 = replay::wave_retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, tid);
+        if (tid == 0) s_n[0] = n1;
+    }
     __syncthreads();
+    const int N1 = s_n[0];
     // the Harris records (and their rpos / ballots) go behind the surviving FAST records when both fit the window
     const size_t b_off = a_lds ? (((size_t)N1 * 4 + 15) & ~(size_t)15) : 0;
     const bool b_lds = b_off + sel_need_bytes(N1, 8) <= SEL_BUF_BYTES;
@@ -549,10 +569,10 @@ __global__ __launch_bounds__(64) void k_select(Plan P, const uint8_t* __restrict
     unsigned long long* b_bl = (unsigned long long*)((uint8_t*)b_rpos + ((((size_t)N1 / 2 + 1) * 2 + 7) & ~(size_t)7));
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
-    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags);
-    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags);
-    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags);
-    else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags);
+    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, s_n);
+    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, s_n);
+    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, s_n);
+    else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, s_n);
 }
 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
@@ -564,7 +584,7 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BUF_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_select, dim3(P.nlevels, batch), dim3(64), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+    hipLaunchKernelGGL(k_select, dim3(P.nlevels, batch), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
                        c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags);
     HIPCHK(c, hipGetLastError());
     return MO_OK;

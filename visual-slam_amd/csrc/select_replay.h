@@ -293,6 +293,16 @@ template <class T, class P> __device__ __forceinline__ int retain_best(P a, int 
 //   L_k = k-th position from the left with !(a > pivot),  R_k = k-th from the right with !(pivot > a)
 //   K   = #{k : L_k < R_k};  swap a[L_k] <-> a[R_k] for k <= K;  cut = min(L_{K+1}, R_K)
 // All 64 lanes call these functions convergently (block = one wavefront).  rpos: u16[>= n/2], bl: u64[>= n/64 + 1].
+// The replay runs on ONE wavefront of a (possibly larger) workgroup, so it must not use workgroup barriers.  Lanes of a
+// wavefront execute in lockstep and LDS / same-CU global accesses of one wavefront are served in issue order; what is
+// needed between a store by one lane and a load of it by another is that the compiler keeps the order and the stores
+// have left the wavefront: a workgroup-scope fence (s_waitcnt, no s_barrier).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 #define REPLAY_SERIAL_BELOW 12  // ranges this short are finished by one lane (a wave partition step costs ~1.5k cycles)
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -333,7 +343,7 @@ __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL
         baseL += __popcll(mL);
         baseR += __popcll(mR);
     }
-    __syncthreads();
+    wave_sync();
     baseL = 0;
     for (int c0 = lo, ch = 0; c0 < hi && baseL < K; c0 += 64, ch++) {
         unsigned long long mL = bl[ch];
@@ -346,7 +356,7 @@ __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL
         }
         baseL += __popcll(mL);
     }
-    __syncthreads();
+    wave_sync();
     if (total_r) *total_r = TR;
     return min(wave_min_i(minNL), wave_min_i(minSR));
 }
@@ -359,13 +369,13 @@ __device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int
     while (last - first > 3) {
         if (last - first < REPLAY_SERIAL_BELOW || last - first > 65535 || depth == 0) {
             if (lane == 0) ls_introselect<T>(a, first, nth, last, depth);  // identical continuation, one lane
-            __syncthreads();
+            wave_sync();
             return;
         }
         --depth;
         int mid = first + (last - first) / 2;
         if (lane == 0) ls_move_median_to_first<T>(a, first, first + 1, mid, last - 1);
-        __syncthreads();
+        wave_sync();
         const T pv = a[first];
         int cut = wave_pair_partition<T>(
             a, first + 1, last, [pv](T v) { return !R::gt(v, pv); }, [pv](T v) { return !R::gt(pv, v); }, rpos, bl, lane,
@@ -374,7 +384,7 @@ __device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int
         else last = cut;
     }
     if (lane == 0) ls_insertion_sort<T>(a, first, last);
-    __syncthreads();
+    wave_sync();
 }
 
 // retainBest, all lanes convergent.  libstdc++ order runs wave-parallel; the MSVC STL's three-way partition is
@@ -386,17 +396,17 @@ __device__ __forceinline__ int wave_retain_best(P a, int n, int n_points, int or
     if (n_points == 0) return 0;
     if (order == MO_ORDER_MSVC) {
         if (lane == 0) ms_nth_element<T>(a, 0, n_points - 1, n);
-        __syncthreads();
+        wave_sync();
     } else {
         wave_ls_nth_element<T>(a, 0, n_points - 1, n, rpos, bl, lane);
     }
     const T amb = a[n_points - 1];
     int tail = n - n_points;
     if (tail < REPLAY_SERIAL_BELOW || tail > 65535) {
-        __shared__ int s_keep;
-        if (lane == 0) s_keep = partition_ge<T>(a, n_points, n, amb);
-        __syncthreads();
-        return n_points + s_keep;
+        int keep = 0;
+        if (lane == 0) keep = partition_ge<T>(a, n_points, n, amb);
+        wave_sync();
+        return n_points + __shfl(keep, 0, 64);
     }
     int total_true = 0;
     wave_pair_partition<T>(
