@@ -274,7 +274,11 @@ __device__ __forceinline__ int arc_score(const int d[16]) {
     d[8] = v - p[-3 * TW];  d[9] = v - p[-3 * TW - 1];  d[10] = v - p[-2 * TW - 2]; d[11] = v - p[-TW - 3];      \
     d[12] = v - p[-3];      d[13] = v - p[TW - 3];      d[14] = v - p[2 * TW - 2];  d[15] = v - p[3 * TW - 1];
 
-// One workgroup = one full-width strip of <= 8 rows of one level of one frame.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+
+// One workgroup = one full-width strip of <= 16 rows of one level of one frame.
 //  1. the strip's pixels (+4 rows / +3 columns of halo) are staged in LDS with aligned dword loads
 //  2. FAST-9 score of every pixel of the strip and its 1-px ring -> u8 score band in LDS (0 = no corner);
 //     work is dealt to the 4 wavefronts in (row, 64-column) units
@@ -321,34 +325,44 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     __syncthreads();
 
     // ---- 2. scores.  With lo = max over the 16 arcs of min(d over the 9-arc) and hi = min over arcs of max(d over arc):
-    // dark corner <=> lo > t, bright corner <=> -hi > t, and cornerScore = max(t, lo, -hi) - 1.  Two 3-input min/max
-    // networks (m3[i] = op(d[i..i+2]), m9[i] = op(m3[i], m3[i+3], m3[i+6])) give test and score at once: no bit masks,
-    // no divergent second pass.
-    const int nxc = (SW + 63) >> 6;
+    // dark corner <=> lo > t, bright corner <=> -hi > t, and cornerScore = max(t, lo, -hi) - 1.  Two min/max networks
+    // (m3[i] = op(d[i..i+2]), m9[i] = op(m3[i], m3[i+3], m3[i+6])) give test and score at once: no bit masks, no divergent
+    // second pass.  Each lane scores TWO horizontally adjacent pixels with packed 16-bit arithmetic (v_pk_sub/min/max_i16).
+    const int nxc = (SW + 127) >> 7;  // 128-column units
     {
         int r = 0, j = wv;
         while (j >= nxc) { j -= nxc; r++; }
         while (r < rows + 2) {
-            const int x = (j << 6) + lane;
+            const int x = (j << 7) + 2 * lane;
             if (x < SW) {
-                const uint8_t* p = &s_tile[(r + 3) * TW + x + 3 + lead];
-                const int v = p[0];
-                int d[16];
-                FAST_LOAD_D(d, v, p, TW)
-                int mn3[16], mx3[16];
+                // volatile: keeps the byte reads separate (merged into a 16-bit ds_read they would sit on odd
+                // addresses half of the time, and misaligned LDS accesses are replayed)
+                typedef const volatile __attribute__((address_space(3))) uint8_t lds_cvu8;
+                lds_cvu8* p = (lds_cvu8*)&s_tile[(r + 3) * TW + x + 3 + lead];
+                const s16x2 v = {(short)p[0], (short)p[1]};
+                s16x2 d[16];
+#define FAST_PAIR(k, o) d[k] = v - (s16x2){(short)p[o], (short)p[(o) + 1]};
+                FAST_PAIR(0, 3 * TW)        FAST_PAIR(1, 3 * TW + 1)    FAST_PAIR(2, 2 * TW + 2)    FAST_PAIR(3, TW + 3)
+                FAST_PAIR(4, 3)             FAST_PAIR(5, -TW + 3)       FAST_PAIR(6, -2 * TW + 2)   FAST_PAIR(7, -3 * TW + 1)
+                FAST_PAIR(8, -3 * TW)       FAST_PAIR(9, -3 * TW - 1)   FAST_PAIR(10, -2 * TW - 2)  FAST_PAIR(11, -TW - 3)
+                FAST_PAIR(12, -3)           FAST_PAIR(13, TW - 3)       FAST_PAIR(14, 2 * TW - 2)   FAST_PAIR(15, 3 * TW - 1)
+#undef FAST_PAIR
+                s16x2 mn3[16], mx3[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    mn3[i] = min(d[i], min(d[(i + 1) & 15], d[(i + 2) & 15]));
-                    mx3[i] = max(d[i], max(d[(i + 1) & 15], d[(i + 2) & 15]));
+                    mn3[i] = pk_min(d[i], pk_min(d[(i + 1) & 15], d[(i + 2) & 15]));
+                    mx3[i] = pk_max(d[i], pk_max(d[(i + 1) & 15], d[(i + 2) & 15]));
                 }
-                int lo = -512, hi = 512;
+                s16x2 lo = {-512, -512}, hi = {512, 512};
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    lo = max(lo, min(mn3[i], min(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
-                    hi = min(hi, max(mx3[i], max(mx3[(i + 3) & 15], mx3[(i + 6) & 15])));
+                    lo = pk_max(lo, pk_min(mn3[i], pk_min(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
+                    hi = pk_min(hi, pk_max(mx3[i], pk_max(mx3[(i + 3) & 15], mx3[(i + 6) & 15])));
                 }
-                const int best = max(lo, -hi);
-                s_score[r * SW + x] = (uint8_t)(best > t ? best - 1 : 0);
+                const s16x2 best = pk_max(lo, -hi);
+                const int b0 = best.x, b1 = best.y;
+                s_score[r * SW + x] = (uint8_t)(b0 > t ? b0 - 1 : 0);
+                if (x + 1 < SW) s_score[r * SW + x + 1] = (uint8_t)(b1 > t ? b1 - 1 : 0);
             }
             j += 4;
             while (j >= nxc) { j -= nxc; r++; }
