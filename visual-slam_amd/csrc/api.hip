@@ -27,13 +27,27 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     if (fresh_timing) mo_stage_begin(c);
     if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels))) return rc;
     mo_stage_mark(c, "pyramid");
+    // the Gaussian blur only depends on the pyramid: it runs on the aux stream beside FAST + selection
+    if (d_desc) {
+        hipStream_t main_s = c->stream;
+        HIPCHK(c, hipEventRecord(c->ev_fork, main_s));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        c->stream = c->aux_stream;
+        if (c->timing) hipEventRecord(c->ev_aux0, c->aux_stream);
+        rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels);
+        if (c->timing) hipEventRecord(c->ev_aux1, c->aux_stream);
+        hipEventRecord(c->ev_join, c->aux_stream);
+        c->stream = main_s;
+        if (rc) return rc;
+    }
     if ((rc = orb_launch_fast(c, d_gray, batch))) return rc;
     mo_stage_mark(c, "fast_nms");
     if ((rc = orb_launch_select(c, d_gray, batch))) return rc;
     mo_stage_mark(c, "select_harris");
     if (d_desc) {
-        if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels))) return rc;
-        mo_stage_mark(c, "blur");
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        mo_stage_mark(c, "blur");  // time taken from the aux-stream events; on the main stream this is only the join
+        c->aux_stage = c->n_stages - 1;
     }
     if ((rc = orb_launch_describe(c, d_gray, batch, d_kps, d_desc, cap, d_counts))) return rc;
     mo_stage_mark(c, "angle_rbrief");

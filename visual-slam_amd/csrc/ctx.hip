@@ -52,6 +52,11 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         return nullptr;
     }
     c->stream = c->own_stream;
+    hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    hipEventCreate(&c->ev_aux0);
+    hipEventCreate(&c->ev_aux1);
     for (int i = 0; i <= MO_NSTAGES; i++) hipEventCreate(&c->ev[i]);
     if (hipMalloc((void**)&c->d_flags, 4 * sizeof(int)) != hipSuccess) {
         g_create_err = "mo_create: hipMalloc failed";
@@ -85,6 +90,8 @@ extern "C" void mo_destroy(mo_ctx* c) {
                     c->d_midx, c->d_mdist, c->d_mpass, c->d_tv, c->d_tmp};
     for (void* b : bufs) if (b) hipFree(b);
     for (int i = 0; i <= MO_NSTAGES; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->ev_fork) { hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); hipEventDestroy(c->ev_aux0); hipEventDestroy(c->ev_aux1); }
+    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -105,6 +112,7 @@ extern "C" int mo_sync(mo_ctx* c) {
 
 void mo_stage_begin(mo_ctx* c) {
     c->n_stages = 0;
+    c->aux_stage = -1;
     if (c->timing) hipEventRecord(c->ev[0], c->stream);
 }
 
@@ -123,6 +131,7 @@ extern "C" int mo_stage_times(mo_ctx* c, const char*** names, float* ms, int cap
     for (int i = 0; i < n; i++) {
         float t = 0;
         hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
+        if (i == c->aux_stage) hipEventElapsedTime(&t, c->ev_aux0, c->ev_aux1);  // stage that ran on the aux stream
         ms[i] = t;
     }
     c->stage_names[c->n_stages] = nullptr;
