@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per rank per step")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches (HIP streams) per GPU")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24)
     args = ap.parse_args()
@@ -131,10 +132,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP front-end has no CPU fallback")
+    local = local % torch.cuda.device_count()  # (rehearsal: several ranks may share one GPU under --backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     from vslam_amd.sharding import gather_map_points, shard
@@ -193,7 +198,7 @@ def main():
         for sb in subs:
             main.wait_stream(sb.stream)
         if world > 1:  # final map-point gather (the only collective on the path)
-            gather_map_points(pts, n_pairs, dst=0)
+            gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0)
         if collect:
             for sb in subs:
                 for name, ms in sb.ctx.stage_times():
@@ -214,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
