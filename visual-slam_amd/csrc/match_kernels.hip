@@ -12,7 +12,8 @@
 #include "common.h"
 
 #define MQ_THREADS 256
-#define MQ_PER_BLOCK 512  // two queries per lane: halves the scalar train-descriptor traffic per distance
+#define MQ_Q 2            // queries per lane (4 leaves too few workgroups at 2000 queries per pair: measured slower)
+#define MQ_PER_BLOCK (MQ_THREADS * MQ_Q)
 #define KEY_NONE 0xFFFFFFFFu
 
 __device__ __forceinline__ void emit_match(uint32_t k0, uint32_t k1, double ratio, size_t o, int32_t* oidx, int32_t* odist,
@@ -40,34 +41,42 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
     const int qfr = qf ? qf[pair] : pair, tfr = tf ? tf[pair] : pair;
     const int nq = counts ? min(counts[qfr], out_stride) : nq_fixed;
     const int nt = counts ? min(counts[tfr], out_stride) : nt_fixed;
-    const int q0 = blockIdx.x * MQ_PER_BLOCK + threadIdx.x, q1 = q0 + MQ_THREADS;
     if (blockIdx.x * MQ_PER_BLOCK >= nq) return;
     const uint32_t* q = (const uint32_t*)(qbase + (size_t)qfr * q_stride);
     const uint32_t* t = (const uint32_t*)(tbase + (size_t)tfr * t_stride);
-    uint32_t a[8], c[8];
-    const int qa = min(q0, nq - 1), qc = min(q1, nq - 1);
+    uint32_t a[MQ_Q][8], k0[MQ_Q], k1[MQ_Q];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { a[k] = q[(size_t)qa * 8 + k]; c[k] = q[(size_t)qc * 8 + k]; }
-    uint32_t ka0 = KEY_NONE, ka1 = KEY_NONE, kc0 = KEY_NONE, kc1 = KEY_NONE;
+    for (int m = 0; m < MQ_Q; m++) {
+        const int qi = min(blockIdx.x * MQ_PER_BLOCK + m * MQ_THREADS + (int)threadIdx.x, nq - 1);
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[m][k] = q[(size_t)qi * 8 + k];
+        k0[m] = KEY_NONE; k1[m] = KEY_NONE;
+    }
 #pragma unroll 4
     for (int j = 0; j < nt; j++) {  // 4 train descriptors (scalar loads) in flight per trip
         const uint32_t* b = t + (size_t)j * 8;  // wave-uniform address -> scalar loads
-        uint32_t da = 0, dc = 0;
+        uint32_t d[MQ_Q];
+#pragma unroll
+        for (int m = 0; m < MQ_Q; m++) d[m] = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t bk = b[k];
-            da += __popc(a[k] ^ bk);
-            dc += __popc(c[k] ^ bk);
+#pragma unroll
+            for (int m = 0; m < MQ_Q; m++) d[m] += __popc(a[m][k] ^ bk);
         }
-        const uint32_t keya = (da << 20) | (uint32_t)j, keyc = (dc << 20) | (uint32_t)j;
-        // new second-best = min(k1, max(k0, key)) given k0 <= k1; new best = min(k0, key)
-        ka1 = min(ka1, max(ka0, keya));
-        ka0 = min(ka0, keya);
-        kc1 = min(kc1, max(kc0, keyc));
-        kc0 = min(kc0, keyc);
+#pragma unroll
+        for (int m = 0; m < MQ_Q; m++) {
+            const uint32_t key = (d[m] << 20) | (uint32_t)j;
+            // new second-best = min(k1, max(k0, key)) given k0 <= k1; new best = min(k0, key)
+            k1[m] = min(k1[m], max(k0[m], key));
+            k0[m] = min(k0[m], key);
+        }
     }
-    if (q0 < nq) emit_match(ka0, ka1, ratio, (size_t)pair * out_stride + q0, oidx, odist, opass);
-    if (q1 < nq) emit_match(kc0, kc1, ratio, (size_t)pair * out_stride + q1, oidx, odist, opass);
+#pragma unroll
+    for (int m = 0; m < MQ_Q; m++) {
+        const int qi = blockIdx.x * MQ_PER_BLOCK + m * MQ_THREADS + threadIdx.x;
+        if (qi < nq) emit_match(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
+    }
 }
 
 int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t q_stride, size_t t_stride,

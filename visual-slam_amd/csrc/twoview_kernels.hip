@@ -259,6 +259,22 @@ __device__ inline double sampson(const double* E, double x1, double y1, double x
     return num * num / den;
 }
 
+// same quantity with the division replaced by v_rcp_f64 + one Newton step (<= 2 ulp): used only for the MSAC ranking of
+// hypotheses, whose cost is compared after rounding to float32
+__device__ inline double sampson_fast(const double* E, double x1, double y1, double x2, double y2) {
+    double ex0 = E[0] * x1 + E[1] * y1 + E[2];
+    double ex1 = E[3] * x1 + E[4] * y1 + E[5];
+    double ex2 = E[6] * x1 + E[7] * y1 + E[8];
+    double et0 = E[0] * x2 + E[3] * y2 + E[6];
+    double et1 = E[1] * x2 + E[4] * y2 + E[7];
+    double num = x2 * ex0 + y2 * ex1 + ex2;
+    double den = ex0 * ex0 + ex1 * ex1 + et0 * et0 + et1 * et1;
+    double r = __builtin_amdgcn_rcp(den);
+    r = fma(fma(-den, r, 1.0), r, r);
+    r = fma(fma(-den, r, 1.0), r, r);
+    return num * num * r;
+}
+
 __device__ inline uint64_t splitmix64(uint64_t& s) {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -430,7 +446,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
         __syncthreads();
         if (valid) {
             for (int i = 0; i < n; i++) {
-                double err = sampson(E, s_pts[4 * i], s_pts[4 * i + 1], s_pts[4 * i + 2], s_pts[4 * i + 3]);
+                double err = sampson_fast(E, s_pts[4 * i], s_pts[4 * i + 1], s_pts[4 * i + 2], s_pts[4 * i + 3]);
                 cost += fmin(err, thr2);
             }
         }
