@@ -376,14 +376,27 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     const int i0 = tid * ipt;
     unsigned long long keep = 0;
     {
+        // sliding 3-column window over the thread's contiguous run: per pixel 3 new byte reads (the column to the right),
+        // keep <=> centre > max(column max left, column max right, up, down) and centre > 0
         int rr = i0 / lv.bw, xx = i0 - rr * lv.bw;
+        const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
+        int cl = max(max((int)s[-SW - 1], (int)s[-1]), (int)s[SW - 1]);   // column x-1
+        int up = s[-SW], mid = s[0], dn = s[SW];                            // column x
         for (int j = 0; j < ipt && i0 + j < nitems; j++) {
-            const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
-            int sc = s[0];
-            if (sc > 0 && sc > s[-1] && sc > s[1] && sc > s[-SW - 1] && sc > s[-SW] && sc > s[-SW + 1] && sc > s[SW - 1] &&
-                sc > s[SW] && sc > s[SW + 1])
-                keep |= 1ull << j;
-            if (++xx == lv.bw) { xx = 0; rr++; }
+            const int up1 = s[-SW + 1], mid1 = s[1], dn1 = s[SW + 1];       // column x+1
+            const int cr = max(max(up1, mid1), dn1);
+            const int nb = max(max(cl, cr), max(up, dn));
+            if (mid > 0 && mid > nb) keep |= 1ull << j;
+            if (++xx == lv.bw) {  // the run wraps to the next row of the strip: restart the window
+                xx = 0; rr++;
+                s = &s_score[(rr + 1) * SW + 1];
+                cl = max(max((int)s[-SW - 1], (int)s[-1]), (int)s[SW - 1]);
+                up = s[-SW]; mid = s[0]; dn = s[SW];
+            } else {
+                cl = max(max(up, mid), dn);
+                up = up1; mid = mid1; dn = dn1;
+                s++;
+            }
         }
     }
     int cnt = __popcll(keep);
