@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     uint8_t* s_score = smem;            // (R+2) rows x SW
     uint8_t* s_tile = smem + score_bytes;
     __shared__ int s_wsum[4];
+    __shared__ uint32_t s_wq[4][192];  // per-wavefront queue of pixels that pass the compass pre-test
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int t = P.fast_threshold;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -324,49 +325,81 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     }
     __syncthreads();
 
-    // ---- 2. scores.  With lo = max over the 16 arcs of min(d over the 9-arc) and hi = min over arcs of max(d over arc):
-    // dark corner <=> lo > t, bright corner <=> -hi > t, and cornerScore = max(t, lo, -hi) - 1.  Two min/max networks
-    // (m3[i] = op(d[i..i+2]), m9[i] = op(m3[i], m3[i+3], m3[i+6])) give test and score at once: no bit masks, no divergent
-    // second pass.  Each lane scores TWO horizontally adjacent pixels with packed 16-bit arithmetic (v_pk_sub/min/max_i16).
-    const int nxc = (SW + 127) >> 7;  // 128-column units
+    // ---- 2. scores.
+    // 2a (every pixel, 5 LDS reads): a 9-arc of the 16-circle always contains >= 2 of the 4 compass pixels, so a pixel
+    //     with fewer than 2 compass pixels darker than v - t AND fewer than 2 brighter than v + t cannot be a corner:
+    //     score 0.  Survivors are appended to a small per-wavefront LDS queue (ballot + prefix popcount).
+    // 2b (survivors only, whenever 128 are queued): with lo = max over arcs of min(d over the 9-arc) and hi = min over
+    //     arcs of max(d over the arc), corner <=> max(lo, -hi) > t and cornerScore = max(t, lo, -hi) - 1.  Each lane scores
+    //     TWO queued pixels with packed 16-bit min/max networks (v_pk_sub/min/max_i16): test and score in one
+    //     branch-free pass over full wavefronts.
+    typedef const volatile __attribute__((address_space(3))) uint8_t lds_cvu8;  // volatile: byte reads stay separate
+    auto score_pair = [&](uint32_t e0, uint32_t e1) {  // queue entry = row << 16 | column
+        const int r0 = e0 >> 16, x0 = e0 & 0xFFFF, r1 = e1 >> 16, x1 = e1 & 0xFFFF;
+        const int pos0 = r0 * SW + x0, pos1 = r1 * SW + x1;
+        lds_cvu8* p = (lds_cvu8*)&s_tile[(r0 + 3) * TW + x0 + 3 + lead];
+        lds_cvu8* q = (lds_cvu8*)&s_tile[(r1 + 3) * TW + x1 + 3 + lead];
+        const s16x2 v = {(short)p[0], (short)q[0]};
+        s16x2 d[16];
+#define FAST_PAIR(k, o) d[k] = v - (s16x2){(short)p[o], (short)q[o]};
+        FAST_PAIR(0, 3 * TW)        FAST_PAIR(1, 3 * TW + 1)    FAST_PAIR(2, 2 * TW + 2)    FAST_PAIR(3, TW + 3)
+        FAST_PAIR(4, 3)             FAST_PAIR(5, -TW + 3)       FAST_PAIR(6, -2 * TW + 2)   FAST_PAIR(7, -3 * TW + 1)
+        FAST_PAIR(8, -3 * TW)       FAST_PAIR(9, -3 * TW - 1)   FAST_PAIR(10, -2 * TW - 2)  FAST_PAIR(11, -TW - 3)
+        FAST_PAIR(12, -3)           FAST_PAIR(13, TW - 3)       FAST_PAIR(14, 2 * TW - 2)   FAST_PAIR(15, 3 * TW - 1)
+#undef FAST_PAIR
+        s16x2 mn3[16], mx3[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            mn3[i] = pk_min(d[i], pk_min(d[(i + 1) & 15], d[(i + 2) & 15]));
+            mx3[i] = pk_max(d[i], pk_max(d[(i + 1) & 15], d[(i + 2) & 15]));
+        }
+        s16x2 lo = {-512, -512}, hi = {512, 512};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            lo = pk_max(lo, pk_min(mn3[i], pk_min(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
+            hi = pk_min(hi, pk_max(mx3[i], pk_max(mx3[(i + 3) & 15], mx3[(i + 6) & 15])));
+        }
+        const s16x2 best = pk_max(lo, -hi);
+        const int b0 = best.x, b1 = best.y;
+        s_score[pos0] = (uint8_t)(b0 > t ? b0 - 1 : 0);
+        s_score[pos1] = (uint8_t)(b1 > t ? b1 - 1 : 0);
+    };
     {
+        uint32_t* wq = s_wq[wv];
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int nxc = (SW + 63) >> 6;
+        int qn = 0;  // wave-uniform queue fill
         int r = 0, j = wv;
         while (j >= nxc) { j -= nxc; r++; }
         while (r < rows + 2) {
-            const int x = (j << 7) + 2 * lane;
+            const int x = (j << 6) + lane;
+            bool pass = false;
+            const int pos = r * SW + x;
             if (x < SW) {
-                // volatile: keeps the byte reads separate (merged into a 16-bit ds_read they would sit on odd
-                // addresses half of the time, and misaligned LDS accesses are replayed)
-                typedef const volatile __attribute__((address_space(3))) uint8_t lds_cvu8;
-                lds_cvu8* p = (lds_cvu8*)&s_tile[(r + 3) * TW + x + 3 + lead];
-                const s16x2 v = {(short)p[0], (short)p[1]};
-                s16x2 d[16];
-#define FAST_PAIR(k, o) d[k] = v - (s16x2){(short)p[o], (short)p[(o) + 1]};
-                FAST_PAIR(0, 3 * TW)        FAST_PAIR(1, 3 * TW + 1)    FAST_PAIR(2, 2 * TW + 2)    FAST_PAIR(3, TW + 3)
-                FAST_PAIR(4, 3)             FAST_PAIR(5, -TW + 3)       FAST_PAIR(6, -2 * TW + 2)   FAST_PAIR(7, -3 * TW + 1)
-                FAST_PAIR(8, -3 * TW)       FAST_PAIR(9, -3 * TW - 1)   FAST_PAIR(10, -2 * TW - 2)  FAST_PAIR(11, -TW - 3)
-                FAST_PAIR(12, -3)           FAST_PAIR(13, TW - 3)       FAST_PAIR(14, 2 * TW - 2)   FAST_PAIR(15, 3 * TW - 1)
-#undef FAST_PAIR
-                s16x2 mn3[16], mx3[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    mn3[i] = pk_min(d[i], pk_min(d[(i + 1) & 15], d[(i + 2) & 15]));
-                    mx3[i] = pk_max(d[i], pk_max(d[(i + 1) & 15], d[(i + 2) & 15]));
-                }
-                s16x2 lo = {-512, -512}, hi = {512, 512};
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    lo = pk_max(lo, pk_min(mn3[i], pk_min(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
-                    hi = pk_min(hi, pk_max(mx3[i], pk_max(mx3[(i + 3) & 15], mx3[(i + 6) & 15])));
-                }
-                const s16x2 best = pk_max(lo, -hi);
-                const int b0 = best.x, b1 = best.y;
-                s_score[r * SW + x] = (uint8_t)(b0 > t ? b0 - 1 : 0);
-                if (x + 1 < SW) s_score[r * SW + x + 1] = (uint8_t)(b1 > t ? b1 - 1 : 0);
+                const uint8_t* p = &s_tile[(r + 3) * TW + x + 3 + lead];
+                const int v = p[0];
+                const int d0 = v - p[3 * TW], d4 = v - p[3], d8 = v - p[-3 * TW], d12 = v - p[-3];
+                const int nd = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
+                const int nb = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
+                pass = nd >= 2 || nb >= 2;
+                if (!pass) s_score[pos] = 0;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) wq[qn + __popcll(m & lt)] = ((uint32_t)r << 16) | (uint32_t)x;
+            qn += __popcll(m);
+            replay::wave_sync();
+            if (qn >= 128) {
+                score_pair(wq[2 * lane], wq[2 * lane + 1]);
+                qn -= 128;
+                const uint32_t carry = wq[128 + lane];  // <= 63 left-over entries move to the front
+                replay::wave_sync();
+                if (lane < qn) wq[lane] = carry;
+                replay::wave_sync();
             }
             j += 4;
             while (j >= nxc) { j -= nxc; r++; }
         }
+        if (2 * lane < qn) score_pair(wq[2 * lane], wq[min(2 * lane + 1, qn - 1)]);
     }
     __syncthreads();
 
