@@ -577,6 +577,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     double tau2_prev = -1.0;
     for (int it = 0; it < 5; it++) {
         double acc[45];
+#pragma unroll
         for (int j = 0; j < 45; j++) acc[j] = 0;
         int cnt = 0;
         double sd = 0;
@@ -603,7 +604,9 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         if (c == c_prev && tau2 == tau2_prev) break;  // same selection size at the same threshold: converged
         c_prev = c; tau2_prev = tau2;
         const double sds = block_sum(sd, s_red);
-        // 45 sums: wave shuffle reduction, per-wave partials in LDS, one barrier
+        // 45 sums: wave shuffle reduction, per-wave partials in LDS, one barrier (unrolled: a dynamic index would
+        // push the accumulators into scratch memory)
+#pragma unroll
         for (int j = 0; j < 45; j++) {
             double v = acc[j];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -74,6 +74,29 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """One process must use ONE HIP runtime.  A PyTorch-ROCm wheel bundles its own libamdhip64; if this library pulled
+    in the system runtime first, a later `import torch` would find "No HIP GPUs".  So when torch is installed (the
+    benchmark and the tests use it for device memory and torch.distributed) and not yet loaded, its runtime is loaded
+    first - by path, without importing torch - and libvslam_amd.so binds to that same copy."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libvslam_amd.so and declare all signatures (does not touch the GPU)."""
     global _lib
@@ -83,6 +106,7 @@ def load_library():
         raise NativeUnavailable(
             "%s is missing: build it with `make -C visual-slam_amd/csrc` (or __graft_entry__.build()). "
             "There is no CPU fallback." % LIB_PATH)
+    _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
