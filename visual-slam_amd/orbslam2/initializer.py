@@ -1,86 +1,125 @@
-"""MapInitializer -- same public surface and return conventions as the reference's src/orbslam2/initializer.py:12-181.
+"""MapInitializer -- drop-in for the reference class of the same name (src/orbslam2/initializer.py:12-181).
 
-initialize() follows the reference step by step (initializer.py:62-152): match -> E (RANSAC, threshold 3.0) ->
-recover pose -> P1, P2 -> keep pose-mask matches -> triangulate -> cheirality filter -> colours -> map-point dicts.
-Every cv2 call in that sequence runs on the MI355X through orbslam2.utils; the list/dict bookkeeping stays Python."""
+Public surface kept: MapInitializer(camera_matrix, min_matches=10, min_inliers_ratio=0.9), set_first_frame(kp, des, image),
+initialize(kp, des, matcher, image) -> (success, R, t, map_points, matches), draw_initialization(img1, img2, matches) and the
+attributes initialization_done / first_frame_* / current_frame_keypoints that Tracker reads (tracker.py:43,106,162,168-170).
+
+What initialize() computes, stage by stage, and where it runs:
+  1. matcher.match(first descriptors, current descriptors)            -> HIP k_match           (initializer.py:67)
+  2. essential matrix, RANSAC threshold 3 px + relative pose           -> HIP two-view kernels  (initializer.py:79-83)
+  3. P1 = K[I|0], P2 = K[R|t]; triangulation of the pose-mask matches  -> HIP DLT kernel        (initializer.py:86-95)
+  4. keep points in front of both cameras, sample colours, build the map-point dictionaries (host bookkeeping)
+Return conventions follow the reference: (False, None, None, None, None) without a first frame, (False, None, None, None,
+matches) when matching or geometry is insufficient, R 3x3 / t 3x1 float64 on success.
+"""
 import numpy as np
 
-from .utils import (triangulate_points, convert_to_3d_points, calculate_essential_matrix, recover_pose,
-                    compute_projection_matrix)
+from . import utils as _geom
+
+
+def _pixels(keypoints, indices):
+    """(N, 2) float32 pixel coordinates of the selected keypoints."""
+    out = np.empty((len(indices), 2), np.float32)
+    for row, i in enumerate(indices):
+        out[row] = keypoints[i].pt
+    return out
 
 
 class MapInitializer:
     def __init__(self, camera_matrix, min_matches=10, min_inliers_ratio=0.9):
         self.camera_matrix = camera_matrix
         self.min_matches = min_matches
-        self.min_inliers_ratio = min_inliers_ratio  # stored and never read, as in the reference (initializer.py:28)
+        self.min_inliers_ratio = min_inliers_ratio  # kept for API parity; the reference never reads it either
         self.initialization_done = False
         self.first_frame_keypoints = None
         self.first_frame_descriptors = None
         self.first_frame_image = None
         self.current_frame_keypoints = None
 
+    # ------------------------------------------------------------------ state
     def set_first_frame(self, keypoints, descriptors, image):
-        self.first_frame_keypoints = keypoints
-        self.first_frame_descriptors = descriptors
-        self.first_frame_image = image.copy()
+        self.first_frame_keypoints, self.first_frame_descriptors = keypoints, descriptors
+        self.first_frame_image = np.array(image, copy=True)  # the caller reuses its frame buffer
         self.initialization_done = False
 
-    def initialize(self, current_keypoints, current_descriptors, matcher, current_image):
-        if self.first_frame_keypoints is None or self.first_frame_descriptors is None:
-            return False, None, None, None, None
-        matches = matcher.match(self.first_frame_descriptors, current_descriptors)
-        if len(matches) < self.min_matches:
-            print(f"Not enough matches for initialization: {len(matches)} < {self.min_matches}")
-            return False, None, None, None, matches
-        points1 = np.float32([self.first_frame_keypoints[m.queryIdx].pt for m in matches])
-        points2 = np.float32([current_keypoints[m.trainIdx].pt for m in matches])
-        E, mask = calculate_essential_matrix(points1, points2, self.camera_matrix, threshold=3.0)
-        if E is None:
-            return False, None, None, None, matches
-        _, R, t, mask_pose, *_ = recover_pose(E, points1, points2, self.camera_matrix, mask)
-        t = t.reshape(3, 1) if t.ndim == 1 else t
-        P1 = compute_projection_matrix(np.eye(3), np.zeros((3, 1)), self.camera_matrix)
-        P2 = compute_projection_matrix(R, t, self.camera_matrix)
-        valid_matches = [m for m, ok in zip(matches, mask_pose.ravel().astype(bool)) if ok]
-        if not valid_matches:  # the reference would raise on its debug prints here (initializer.py:100)
-            return False, None, None, None, valid_matches
-        points1 = np.float32([self.first_frame_keypoints[m.queryIdx].pt for m in valid_matches])
-        points2 = np.float32([current_keypoints[m.trainIdx].pt for m in valid_matches])
-        points_4d = triangulate_points(points1, points2, P1, P2)
-        points_3d = convert_to_3d_points(points_4d)
-        # points in front of both cameras (initializer.py:105-120)
-        depth2 = (points_3d.astype(np.float64) @ R.T + t.ravel())[:, 2]
-        valid_indices = [i for i in range(len(points_3d)) if points_3d[i, 2] > 0 and depth2[i] > 0]
-        points_3d = points_3d[valid_indices]
-        valid_matches = [valid_matches[i] for i in valid_indices]
-        if len(points_3d) < self.min_matches // 2:
-            print(f"Insufficient valid 3D points after filtering: {len(points_3d)}")
-            return False, None, None, None, valid_matches
-        img = self.first_frame_image
-        colors = []
-        for m in valid_matches:
-            kp = self.first_frame_keypoints[m.queryIdx]
-            x, y = int(kp.pt[0]), int(kp.pt[1])
-            if 0 <= x < img.shape[1] and 0 <= y < img.shape[0]:
-                colors.append(img[y, x, :] if img.ndim == 3 else np.array([img[y, x]] * 3))
-            else:
-                colors.append(np.array([0, 0, 255]))
-        initial_map_points = [{'position': pt, 'color': colors[i],
-                               'keypoint_references': {0: m.queryIdx, 1: m.trainIdx},
-                               'observed_frames': [0, 1]}
-                              for i, (pt, m) in enumerate(zip(points_3d, valid_matches))]
-        self.initialization_done = True
-        self.current_frame_keypoints = current_keypoints
-        return True, R, t, initial_map_points, valid_matches
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _failure(matches):
+        return False, None, None, None, matches
 
+    def _colours(self, keypoints, query_indices):
+        """Colour of the first frame under each reference keypoint (BGR triple; grey replicated; red when outside)."""
+        img = self.first_frame_image
+        h, w = img.shape[:2]
+        colours = []
+        for qi in query_indices:
+            px, py = (int(v) for v in keypoints[qi].pt)
+            if not (0 <= px < w and 0 <= py < h):
+                colours.append(np.array([0, 0, 255]))
+            elif img.ndim == 3:
+                colours.append(img[py, px, :])
+            else:
+                colours.append(np.array([img[py, px]] * 3))
+        return colours
+
+    # ------------------------------------------------------------------ the hot path
+    def initialize(self, current_keypoints, current_descriptors, matcher, current_image):
+        ref_kps, ref_desc = self.first_frame_keypoints, self.first_frame_descriptors
+        if ref_kps is None or ref_desc is None:
+            return self._failure(None)
+
+        putative = matcher.match(ref_desc, current_descriptors)
+        if len(putative) < self.min_matches:
+            print(f"Not enough matches for initialization: {len(putative)} < {self.min_matches}")
+            return self._failure(putative)
+
+        K = self.camera_matrix
+        xy_ref = _pixels(ref_kps, [m.queryIdx for m in putative])
+        xy_cur = _pixels(current_keypoints, [m.trainIdx for m in putative])
+        E, ransac_mask = _geom.calculate_essential_matrix(xy_ref, xy_cur, K, threshold=3.0)
+        if E is None:
+            return self._failure(putative)
+        _, R, t, pose_mask = _geom.recover_pose(E, xy_ref, xy_cur, K, ransac_mask)
+        t = np.asarray(t, np.float64).reshape(3, 1)
+
+        keep = np.flatnonzero(np.asarray(pose_mask).ravel())
+        survivors = [putative[i] for i in keep]
+        if not survivors:  # (the reference would raise on its debug prints here)
+            return self._failure(survivors)
+
+        P_ref = _geom.compute_projection_matrix(np.eye(3), np.zeros((3, 1)), K)
+        P_cur = _geom.compute_projection_matrix(R, t, K)
+        X = _geom.convert_to_3d_points(_geom.triangulate_points(xy_ref[keep], xy_cur[keep], P_ref, P_cur))
+
+        # cheirality: positive depth in the first camera and in the second one (X' = R X + t)
+        depth_cur = (X.astype(np.float64) @ R.T + t.ravel())[:, 2]
+        front = np.flatnonzero((X[:, 2] > 0) & (depth_cur > 0))
+        X = X[front]
+        survivors = [survivors[i] for i in front]
+        if len(X) < self.min_matches // 2:
+            print(f"Insufficient valid 3D points after filtering: {len(X)}")
+            return self._failure(survivors)
+
+        colours = self._colours(ref_kps, [m.queryIdx for m in survivors])
+        map_points = []
+        for position, colour, m in zip(X, colours, survivors):
+            map_points.append({"position": position, "color": colour,
+                               "keypoint_references": {0: m.queryIdx, 1: m.trainIdx}, "observed_frames": [0, 1]})
+
+        self.current_frame_keypoints = current_keypoints
+        self.initialization_done = True
+        return True, R, t, map_points, survivors
+
+    # ------------------------------------------------------------------ visualisation (needs cv2; not on the HIP path)
     def draw_initialization(self, first_image, current_image, matches):
         from .types import HAVE_CV2
         if not HAVE_CV2:
             raise RuntimeError("draw_initialization is visualisation and needs cv2 (out of scope of the HIP path)")
         import cv2
-        a = cv2.cvtColor(first_image, cv2.COLOR_GRAY2BGR) if first_image.ndim == 2 else first_image.copy()
-        b = cv2.cvtColor(current_image, cv2.COLOR_GRAY2BGR) if current_image.ndim == 2 else current_image.copy()
-        return cv2.drawMatches(a, self.first_frame_keypoints, b, self.current_frame_keypoints, matches, None,
-                               flags=cv2.DrawMatchesFlags_NOT_DRAW_SINGLE_POINTS, matchColor=(0, 255, 0),
-                               singlePointColor=(255, 0, 0))
+
+        def as_bgr(img):
+            return cv2.cvtColor(img, cv2.COLOR_GRAY2BGR) if img.ndim == 2 else img.copy()
+
+        return cv2.drawMatches(as_bgr(first_image), self.first_frame_keypoints, as_bgr(current_image),
+                               self.current_frame_keypoints, matches, None, matchColor=(0, 255, 0),
+                               singlePointColor=(255, 0, 0), flags=cv2.DrawMatchesFlags_NOT_DRAW_SINGLE_POINTS)
