@@ -52,7 +52,12 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         return nullptr;
     }
     c->stream = c->own_stream;
-    hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    {   // the auxiliary stream only fills idle CUs: lowest priority, so FAST + selection on the main stream keep theirs
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess)
+            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    }
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipEventCreate(&c->ev_aux0);
