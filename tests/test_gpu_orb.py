@@ -209,3 +209,26 @@ def test_bad_arguments_fail_loudly(ctx):
     bad.wta_k = 3
     with pytest.raises(V.NativeError):
         ctx.orb_detect_compute(np.zeros((480, 640), np.uint8), bad)
+
+
+def test_capacity_retry_and_huge_nfeatures(ctx, O):
+    """cap smaller than the result -> MO_ERR_CAPACITY with the needed counts (the binding retries); nfeatures larger than
+    the number of corners -> no retainBest at all, raster order per level."""
+    import ctypes as C
+    import vslam_amd as V
+    img = synthetic_frame(13)
+    p, o = _prm(V, O, V.ORDER_LIBSTDCXX, nfeatures=1500)
+    O.lib().orc_set_variant(0, 0)
+    kps = np.zeros((1, 100), V.KP_DTYPE); desc = np.zeros((1, 100, 32), np.uint8); counts = np.zeros(1, np.int32)
+    rc = ctx.lib.mo_orb_detect_compute(ctx.h, C.byref(p), img.ctypes.data_as(C.c_void_p), 640, 480, 640, 1, 1,
+                                       kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.c_void_p), 100,
+                                       counts.ctypes.data_as(C.c_void_p))
+    assert rc == V.MO_ERR_CAPACITY and counts[0] == 1500
+    (k, d), = ctx.orb_detect_compute(img, p, cap=100)   # wrapper grows the buffers and retries
+    ek, ed = O.detect_and_compute(img, o)
+    assert len(k) == 1500 and np.array_equal(d, ed)
+    p, o = _prm(V, O, V.ORDER_LIBSTDCXX, nfeatures=200000, fast_threshold=20)
+    (k, d), = ctx.orb_detect_compute(img, p, cap=60000)
+    ek, ed = O.detect_and_compute(img, o)
+    assert len(k) == len(ek) and np.array_equal(k["x"], ek["x"]) and np.array_equal(k["y"], ek["y"]) and np.array_equal(d, ed)
+    O.lib().orc_set_variant(1, 0)
