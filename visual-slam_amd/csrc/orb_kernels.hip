@@ -278,7 +278,7 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
-// One workgroup = one full-width strip of <= 16 rows of one level of one frame.
+// One workgroup = one full-width strip of <= 8 rows of one level of one frame.
 //  1. the strip's pixels (+4 rows / +3 columns of halo) are staged in LDS with aligned dword loads
 //  2. FAST-9 score of every pixel of the strip and its 1-px ring -> u8 score band in LDS (0 = no corner);
 //     work is dealt to the 4 wavefronts in (row, 64-column) units
