@@ -279,7 +279,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         fin_off += v.fin_cap;
         v.scr_off = scr_off;
         // u64 records B + u32 records A + u16 partner positions + u64 ballots, in u64 units
-        scr_off += v.cand_cap + (v.cand_cap + 1) / 2 + (v.cand_cap / 2 + 8) / 4 + 2 + v.cand_cap / 64 + 4;
+        scr_off += v.cand_cap + (v.cand_cap + 1) / 2 + (v.cand_cap / 2 + 8) / 4 + 2 + v.cand_cap / 64 + 12;
     }
     P.pyr_stride = std::max(pyr_off, 256);
     P.blur_stride = blur_off;

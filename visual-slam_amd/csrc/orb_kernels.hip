@@ -525,7 +525,7 @@ __device__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) 
 // Record window layout (LDS, SEL_BUF_BYTES): [records | rpos u16 x n/2 | ballots u64 x (n/64 + 1)]; the same layout is
 // used inside the level's HBM scratch slot when a level has more candidates than the window holds.
 __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
-    return (((size_t)n * rec_bytes + 7) & ~(size_t)7) + ((((size_t)n / 2 + 1) * 2 + 7) & ~(size_t)7) + ((size_t)n / 64 + 2) * 8;
+    return (((size_t)n * rec_bytes + 7) & ~(size_t)7) + ((((size_t)n / 2 + 1) * 2 + 7) & ~(size_t)7) + ((size_t)n / 64 + 8) * 8;
 }
 
 #define SEL_THREADS 256
@@ -663,7 +663,7 @@ __global__ __launch_bounds__(64) void k_retain_probe(const float* resp, int n, i
 
 int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order, int* d_nout) {
     size_t nn = (size_t)std::max(n, 1);
-    size_t rec_b = nn * sizeof(uint64_t), rpos_b = ((nn / 2 + 4) * 2 + 7) & ~(size_t)7, bl_b = (nn / 64 + 2) * 8;
+    size_t rec_b = nn * sizeof(uint64_t), rpos_b = ((nn / 2 + 4) * 2 + 7) & ~(size_t)7, bl_b = (nn / 64 + 8) * 8;
     int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, rec_b + rpos_b + bl_b);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)c->d_tmp;

@@ -292,7 +292,7 @@ template <class T, class P> __device__ __forceinline__ int retain_best(P a, int 
 // and reproduces the serial permutation exactly:
 //   L_k = k-th position from the left with !(a > pivot),  R_k = k-th from the right with !(pivot > a)
 //   K   = #{k : L_k < R_k};  swap a[L_k] <-> a[R_k] for k <= K;  cut = min(L_{K+1}, R_K)
-// All 64 lanes call these functions convergently (block = one wavefront).  rpos: u16[>= n/2], bl: u64[>= n/64 + 1].
+// All 64 lanes of ONE wavefront call these functions convergently.  rpos: u16[>= n/2], bl: u64[>= n/64 + 8].
 // The replay runs on ONE wavefront of a (possibly larger) workgroup, so it must not use workgroup barriers.  Lanes of a
 // wavefront execute in lockstep and LDS / same-CU global accesses of one wavefront are served in issue order; what is
 // needed between a store by one lane and a load of it by another is that the compiler keeps the order and the stores
@@ -311,50 +311,93 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return v;
 }
 
-// generic pairing partition: stopL(v) / stopR(v) classify an element; returns cut (absolute index) and total of R
+// generic pairing partition: stopL(v) / stopR(v) classify an element; returns cut (absolute index) and total of R.
+// Each lane handles 4 consecutive elements per trip (256 per wavefront trip): element index = c0 + 4*lane + k, so the
+// rank of an element is (stoppers in earlier trips) + (stoppers of lower lanes, any k) + (own stoppers with smaller k).
+// bl: one ballot per (trip, k) -> u64[4 * ceil(n / 256)].
+#define RP_EPL 4
 template <class T, class P, class FL, class FR>
 __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
                                    int lane, int* total_r) {
     const unsigned long long lt = (1ull << lane) - 1ull;
     int TR = 0;
-    for (int c0 = lo, ch = 0; c0 < hi; c0 += 64, ch++) {
-        int i = c0 + lane;
-        bool in = i < hi;
-        T v = a[in ? i : lo];
-        unsigned long long mL = __ballot(in && stopL(v)), mR = __ballot(in && stopR(v));
-        if (lane == 0) bl[ch] = mL;
-        TR += __popcll(mR);
+    for (int c0 = lo, ch = 0; c0 < hi; c0 += 64 * RP_EPL, ch++) {
+        T v[RP_EPL];
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            int i = c0 + RP_EPL * lane + k;
+            v[k] = a[i < hi ? i : lo];
+        }
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            bool in = c0 + RP_EPL * lane + k < hi;
+            unsigned long long mL = __ballot(in && stopL(v[k])), mR = __ballot(in && stopR(v[k]));
+            if (lane == 0) bl[ch * RP_EPL + k] = mL;
+            TR += __popcll(mR);
+        }
     }
     int baseL = 0, baseR = 0, K = 0, minNL = 0x7FFFFFFF, minSR = 0x7FFFFFFF;
-    for (int c0 = lo; c0 < hi; c0 += 64) {
-        int i = c0 + lane;
-        bool in = i < hi;
-        T v = a[in ? i : lo];
-        bool isL = in && stopL(v), isR = in && stopR(v);
-        unsigned long long mL = __ballot(isL), mR = __ballot(isR);
-        int cL = baseL + __popcll(mL & lt), cR = baseR + __popcll(mR & lt);
-        int kL = cL + 1, kR = TR - cR;
-        bool swL = isL && (TR - cR - (isR ? 1 : 0)) >= kL;   // R_kL lies strictly right of this element
-        bool swR = isR && cL >= kR;                          // L_kR lies strictly left of this element
-        if (swR) rpos[kR - 1] = (uint16_t)(i - lo);
-        if (isL && !swL) minNL = min(minNL, i);
-        if (swR) minSR = min(minSR, i);
-        K += __popcll(__ballot(swL));
-        baseL += __popcll(mL);
-        baseR += __popcll(mR);
+    for (int c0 = lo; c0 < hi; c0 += 64 * RP_EPL) {
+        T v[RP_EPL];
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            int i = c0 + RP_EPL * lane + k;
+            v[k] = a[i < hi ? i : lo];
+        }
+        bool isL[RP_EPL], isR[RP_EPL];
+        int pl = 0, pr = 0, tl = 0, tr = 0;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            bool in = c0 + RP_EPL * lane + k < hi;
+            isL[k] = in && stopL(v[k]);
+            isR[k] = in && stopR(v[k]);
+            unsigned long long mL = __ballot(isL[k]), mR = __ballot(isR[k]);
+            pl += __popcll(mL & lt); pr += __popcll(mR & lt);
+            tl += __popcll(mL); tr += __popcll(mR);
+        }
+        int cL = baseL + pl, cR = baseR + pr;   // stoppers strictly before this lane's first element
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            const int i = c0 + RP_EPL * lane + k;
+            const int kL = cL + 1, kR = TR - cR;
+            const bool swL = isL[k] && (TR - cR - (isR[k] ? 1 : 0)) >= kL;   // R_kL lies strictly right of this element
+            const bool swR = isR[k] && cL >= kR;                              // L_kR lies strictly left of this element
+            if (swR) rpos[kR - 1] = (uint16_t)(i - lo);
+            if (isL[k] && !swL) minNL = min(minNL, i);
+            if (swR) minSR = min(minSR, i);
+            K += __popcll(__ballot(swL));
+            cL += isL[k] ? 1 : 0;
+            cR += isR[k] ? 1 : 0;
+        }
+        baseL += tl;
+        baseR += tr;
     }
     wave_sync();
     baseL = 0;
-    for (int c0 = lo, ch = 0; c0 < hi && baseL < K; c0 += 64, ch++) {
-        unsigned long long mL = bl[ch];
-        int kL = baseL + __popcll(mL & lt) + 1;
-        if (((mL >> lane) & 1ull) && kL <= K) {
-            int p = c0 + lane, q = lo + rpos[kL - 1];
-            T vp = a[p], vq = a[q];
-            a[p] = vq;
-            a[q] = vp;
+    for (int c0 = lo, ch = 0; c0 < hi && baseL < K; c0 += 64 * RP_EPL, ch++) {
+        unsigned long long mL[RP_EPL];
+        int pl = 0, tl = 0;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            mL[k] = bl[ch * RP_EPL + k];
+            pl += __popcll(mL[k] & lt);
+            tl += __popcll(mL[k]);
         }
-        baseL += __popcll(mL);
+        int cL = baseL + pl;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            if ((mL[k] >> lane) & 1ull) {
+                const int kL = cL + 1;
+                if (kL <= K) {
+                    int p = c0 + RP_EPL * lane + k, q = lo + rpos[kL - 1];
+                    T vp = a[p], vq = a[q];
+                    a[p] = vq;
+                    a[q] = vp;
+                }
+                cL++;
+            }
+        }
+        baseL += tl;
     }
     wave_sync();
     if (total_r) *total_r = TR;
