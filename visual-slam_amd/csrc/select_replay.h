@@ -303,7 +303,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-#define REPLAY_SERIAL_BELOW 12  // ranges this short are finished by one lane (a wave partition step costs ~1.5k cycles)
+#define REPLAY_SERIAL_BELOW 32  // ranges this short are finished by one lane (a wave partition step costs ~1.5k cycles)
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -336,9 +336,13 @@ __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL
             TR += __popcll(mR);
         }
     }
+    // cut = min(first non-swapping left stopper, last swapping right stopper = smallest swapping-R position): positions grow
+    // with (trip, lane, k), so the first trip in which any lane holds one decides, and the lowest such lane holds the minimum
     int baseL = 0, baseR = 0, K = 0, minNL = 0x7FFFFFFF, minSR = 0x7FFFFFFF;
+    bool foundNL = false, foundSR = false;
     for (int c0 = lo; c0 < hi; c0 += 64 * RP_EPL) {
         T v[RP_EPL];
+        int nl_pos = 0x7FFFFFFF, sr_pos = 0x7FFFFFFF;
 #pragma unroll
         for (int k = 0; k < RP_EPL; k++) {
             int i = c0 + RP_EPL * lane + k;
@@ -363,11 +367,19 @@ __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL
             const bool swL = isL[k] && (TR - cR - (isR[k] ? 1 : 0)) >= kL;   // R_kL lies strictly right of this element
             const bool swR = isR[k] && cL >= kR;                              // L_kR lies strictly left of this element
             if (swR) rpos[kR - 1] = (uint16_t)(i - lo);
-            if (isL[k] && !swL) minNL = min(minNL, i);
-            if (swR) minSR = min(minSR, i);
+            if (isL[k] && !swL) nl_pos = min(nl_pos, i);
+            if (swR) sr_pos = min(sr_pos, i);
             K += __popcll(__ballot(swL));
             cL += isL[k] ? 1 : 0;
             cR += isR[k] ? 1 : 0;
+        }
+        if (!foundNL) {
+            unsigned long long mk = __ballot(nl_pos != 0x7FFFFFFF);
+            if (mk) { minNL = __builtin_amdgcn_readlane(nl_pos, __ffsll((long long)mk) - 1); foundNL = true; }
+        }
+        if (!foundSR) {
+            unsigned long long mk = __ballot(sr_pos != 0x7FFFFFFF);
+            if (mk) { minSR = __builtin_amdgcn_readlane(sr_pos, __ffsll((long long)mk) - 1); foundSR = true; }
         }
         baseL += tl;
         baseR += tr;
@@ -401,7 +413,7 @@ __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL
     }
     wave_sync();
     if (total_r) *total_r = TR;
-    return min(wave_min_i(minNL), wave_min_i(minSR));
+    return min(minNL, minSR);
 }
 
 template <class T, class P>
