@@ -570,11 +570,12 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
 __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                         const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
                                                         uint64_t* __restrict__ scratch, size_t scratch_stride,
-                                                        FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // SEL_BUF_BYTES
+                                                        FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags,
+                                                        int level0, int buf_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less)
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
     __shared__ int s_n[2];
-    const int L = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int L = level0 + blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
     if (lv.nstrips == 0) {
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     uint32_t* gA = (uint32_t*)(scr + lv.cand_cap);
     uint16_t* g_rpos = (uint16_t*)(gA + lv.cand_cap + (lv.cand_cap & 1));
     unsigned long long* g_bl = (unsigned long long*)(g_rpos + (((size_t)lv.cand_cap / 2 + 4) & ~(size_t)3));
-    const bool a_lds = sel_need_bytes(N, 4) <= SEL_BUF_BYTES;
+    const bool a_lds = sel_need_bytes(N, 4) <= (size_t)buf_bytes;
     uint32_t* s_A = (uint32_t*)s_buf;
     uint16_t* a_rpos = (uint16_t*)(s_buf + (((size_t)N * 4 + 7) & ~(size_t)7));
     unsigned long long* a_bl = (unsigned long long*)((uint8_t*)a_rpos + ((((size_t)N / 2 + 1) * 2 + 7) & ~(size_t)7));
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     const int N1 = s_n[0];
     // the Harris records (and their rpos / ballots) go behind the surviving FAST records when both fit the window
     const size_t b_off = a_lds ? (((size_t)N1 * 4 + 15) & ~(size_t)15) : 0;
-    const bool b_lds = b_off + sel_need_bytes(N1, 8) <= SEL_BUF_BYTES;
+    const bool b_lds = b_off + sel_need_bytes(N1, 8) <= (size_t)buf_bytes;
     uint64_t* s_B = (uint64_t*)(s_buf + b_off);
     uint16_t* b_rpos = (uint16_t*)((uint8_t*)s_B + (size_t)N1 * 8);
     unsigned long long* b_bl = (unsigned long long*)((uint8_t*)b_rpos + ((((size_t)N1 / 2 + 1) * 2 + 7) & ~(size_t)7));
@@ -644,8 +645,18 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BUF_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_select, dim3(P.nlevels, batch), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
-                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags);
+    // Two launches: the fine levels (most candidates) get the full LDS record window, the coarse levels (less than a third
+    // of level 0's pixels) a quarter of it, so four times as many of their workgroups are resident.  The replays are
+    // latency-bound single wavefronts: residency is what buys throughput.  A level that outgrows its window falls back to
+    // its HBM scratch slot (same code, slower).
+    int split = 1;
+    while (split < P.nlevels && (long long)P.lv[split].w * P.lv[split].h * 3 > (long long)P.lv[0].w * P.lv[0].h) split++;
+    hipLaunchKernelGGL(k_select, dim3(split, batch), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags, 0, SEL_BUF_BYTES);
+    if (split < P.nlevels)
+        hipLaunchKernelGGL(k_select, dim3(P.nlevels - split, batch), dim3(SEL_THREADS), SEL_BUF_BYTES / 4, c->stream, P, d_gray,
+                           c->d_pyr, c->d_cand, c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt,
+                           c->d_flags, split, SEL_BUF_BYTES / 4);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
