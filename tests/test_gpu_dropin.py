@@ -210,3 +210,23 @@ def test_tracker_call_sequence():
     assert len(m) > 100
     d = np.array([np.array(kp2[x.trainIdx].pt) - np.array(kp1[x.queryIdx].pt) for x in m])
     assert np.abs(np.median(d[:, 0]) + 5) < 1.0 and np.abs(np.median(d[:, 1])) < 1.0   # the 5 px pan is recovered
+
+
+def test_example_frame_loop_runs():
+    """visual-slam_amd/examples/run_frames.py: tester_map-style loop on the drop-in classes; the sideways-moving camera
+    must be recovered (|t_x| ~ 1) on most tracked frames."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visual-slam_amd", "examples", "run_frames.py")
+    spec = importlib.util.spec_from_file_location("run_frames", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv, sys.argv = sys.argv, ["run_frames.py", "--frames", "8"]
+    try:
+        state, poses, n_map = mod.main()
+    finally:
+        sys.argv = argv
+    assert state == "TRACKING" and n_map > 100 and len(poses) >= 6
+    tx = np.array([abs(float(t.ravel()[0])) for _, t in poses])
+    assert (tx > 0.95).mean() > 0.7
