@@ -97,14 +97,8 @@ extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const ui
     if ((rc = reserve_out(c, batch, cap))) return rc;
     if ((rc = run_extract(c, p, d_gray, w, h, batch, c->d_kps, desc ? c->d_desc : nullptr, cap, c->d_counts, true))) return rc;
     HIPCHK(c, hipMemcpyAsync(counts, c->d_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    rc = check_flags(c);
-    if (rc && rc != MO_ERR_CAPACITY) return rc;
-    if (rc == MO_ERR_CAPACITY) {
-        bool user_cap = false;
-        for (int f = 0; f < batch; f++) user_cap |= counts[f] > cap;
-        if (!user_cap) return rc;  // internal capacity
-        return rc;
-    }
+    rc = check_flags(c);  // MO_ERR_CAPACITY: counts already holds the sizes a retry needs
+    if (rc) return rc;
     for (int f = 0; f < batch; f++) {
         int n = std::min(counts[f], cap);
         if (n <= 0) continue;

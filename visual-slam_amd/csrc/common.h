@@ -81,6 +81,7 @@ struct mo_ctx {
     FinalKp* d_fin = nullptr;      // [batch][fin_stride]
     int* d_fin_cnt = nullptr;      // [batch][MO_MAX_LEVELS]
     int* d_flags = nullptr;        // [4] error flags raised by kernels
+    unsigned lds_attr_done = 0;    // bit per kernel whose max-dynamic-LDS attribute has been raised on this device
     // output staging for the host API
     mo_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int* d_counts = nullptr; int out_cap = 0, out_batch = 0;
     // matcher staging

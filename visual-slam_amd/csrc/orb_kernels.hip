@@ -462,10 +462,10 @@ template <int TW> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, in
     const Plan& P = c->plan;
     size_t lds = score_bytes + (size_t)(max_rows + 8) * TW + 16;
     if (lds > 128 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
-    static bool attr_set = false;
-    if (!attr_set) {
+    const unsigned bit = TW == 704 ? 1u : TW == 1344 ? 2u : TW == 2112 ? 4u : 8u;
+    if (!(c->lds_attr_done & bit)) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_fast<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
+        c->lds_attr_done |= bit;
     }
     hipLaunchKernelGGL(k_fast<TW>, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr, c->d_cand,
                        c->d_strip_cnt, (int)score_bytes);
@@ -640,10 +640,9 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
     const Plan& P = c->plan;
     for (int L = 0; L < P.nlevels; L++)
         if (P.lv[L].nstrips > SEL_MAXSTRIPS) return mo_fail(c, MO_ERR_UNSUPPORTED, "too many strips per level");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(c->lds_attr_done & 16u)) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BUF_BYTES));
-        attr_set = true;
+        c->lds_attr_done |= 16u;
     }
     // Two launches: the fine levels (most candidates) get the full LDS record window, the coarse levels (less than a third
     // of level 0's pixels) a quarter of it, so four times as many of their workgroups are resident.  The replays are
