@@ -750,31 +750,33 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
 #define DP_BLR_PITCH 44   // 39 columns + <= 3 alignment lead-in, 11 dwords
 #define DP_WAVE_BYTES (31 * DP_RAW_PITCH + 39 * DP_BLR_PITCH)
 
-// stage a rows x ndw-dword window whose first column is x0a (a multiple of 4) into a half-wave-private LDS patch;
-// hl = lane within the 32-lane half: 16 lanes per row (ndw <= 11 active), 2 rows per trip
+#define DG 16                 // lanes per keypoint (a quarter of a wavefront)
+#define DK_PER_WG (256 / DG)  // keypoints per 256-thread workgroup
+
+// stage a rows x ndw-dword window whose first column is x0a (a multiple of 4) into a group-private LDS patch;
+// gl = lane within the DG-lane group: one row per trip, ndw <= 11 of the 16 lanes active
 __device__ __forceinline__ void stage_patch(const uint8_t* img, int pitch, int x0a, int y0, int rows, int ndw, uint8_t* dst,
-                                            int dpitch, int hl, bool aligned) {
+                                            int dpitch, int gl, bool aligned) {
     if (aligned) {
-        const int c4 = hl & 15;
-        if (c4 < ndw)
-            for (int r = hl >> 4; r < rows; r += 2)
-                *(uint32_t*)(dst + r * dpitch + 4 * c4) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * c4);
+        if (gl < ndw)
+            for (int r = 0; r < rows; r++)
+                *(uint32_t*)(dst + r * dpitch + 4 * gl) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * gl);
     } else {
-        for (int i = hl; i < rows * ndw * 4; i += 32) {
+        for (int i = gl; i < rows * ndw * 4; i += DG) {
             int r = i / (ndw * 4), cidx = i - r * (ndw * 4);
             dst[r * dpitch + cidx] = (x0a + cidx < pitch) ? img[(size_t)(y0 + r) * pitch + x0a + cidx] : 0;
         }
     }
 }
 
-__device__ __forceinline__ int half_sum(int v) {  // sum over the 32 lanes of a half-wavefront
+__device__ __forceinline__ int group_sum(int v) {  // sum over the DG lanes of a keypoint group
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = DG / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-// 256 rotated binary tests from an LDS patch, 8 per lane of a half-wavefront: lane hl produces descriptor byte hl
-__device__ __forceinline__ uint8_t rbrief_byte(const uint8_t* patch, int ppitch, int cx, int cy, float angle_deg, int hl) {
+// 256 rotated binary tests from an LDS patch, 16 per lane of a 16-lane group: lane gl produces descriptor bytes 2gl, 2gl+1
+__device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch, int cx, int cy, float angle_deg, int gl) {
     float angle = angle_deg;
     angle *= (float)(3.14159265358979323846 / 180.f);
     double sd, cd;
@@ -782,8 +784,8 @@ __device__ __forceinline__ uint8_t rbrief_byte(const uint8_t* patch, int ppitch,
     const float a = (float)cd, b = (float)sd;
     unsigned val = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int8_t* pt = &c_pattern[(hl * 8 + k) * 4];
+    for (int k = 0; k < 16; k++) {
+        const int8_t* pt = &c_pattern[(gl * 16 + k) * 4];
         float fx0 = (float)pt[0], fy0 = (float)pt[1], fx1 = (float)pt[2], fy1 = (float)pt[3];
         int ix0 = __float2int_rn(fx0 * a - fy0 * b), iy0 = __float2int_rn(fx0 * b + fy0 * a);
         int ix1 = __float2int_rn(fx1 * a - fy1 * b), iy1 = __float2int_rn(fx1 * b + fy1 * a);
@@ -791,15 +793,13 @@ __device__ __forceinline__ uint8_t rbrief_byte(const uint8_t* patch, int ppitch,
         int t1 = patch[(cy + iy1) * ppitch + cx + ix1];
         val |= (t0 < t1 ? 1u : 0u) << k;
     }
-    return (uint8_t)val;
+    return (uint16_t)val;  // little endian: bits 0..7 = byte 2gl, bits 8..15 = byte 2gl+1
 }
 
-#define DK_PER_WG 8  // keypoints per 256-thread workgroup: one per half-wavefront
-
-// One HALF-wavefront (32 lanes) per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred patch
-// (rBRIEF) are staged in LDS with aligned dword loads; orientation sums and the 256 rotated tests then read LDS only.
-// Pairing two keypoints per wavefront shares the instruction stream of the per-keypoint scalar work (level lookup,
-// fastAtan2, the f64 sincos) between them.
+// One 16-lane group (a quarter wavefront) per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred
+// patch (rBRIEF) are staged in LDS with aligned dword loads; orientation sums and the 256 rotated tests then read LDS only.
+// Four keypoints share one wavefront's instruction stream for the per-keypoint scalar work (level lookup, fastAtan2, the
+// f64 sincos): the kernel is instruction-bound, so this is what sets its speed.
 __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                                   const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
@@ -807,8 +807,8 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
                                                   int* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_WAVE_BYTES];
     const int frame = blockIdx.y;
-    const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
-    const int k = blockIdx.x * DK_PER_WG + half;
+    const int grp = threadIdx.x / DG, gl = threadIdx.x % DG;
+    const int k = blockIdx.x * DK_PER_WG + grp;
     const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
     int total = 0, L = -1, idx = 0;
     for (int l = 0; l < P.nlevels; l++) {
@@ -816,12 +816,12 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         if (L < 0 && k < total + n) { L = l; idx = k - total; }
         total += n;
     }
-    if (k == 0 && hl == 0) {
+    if (k == 0 && gl == 0) {
         counts[frame] = total;
         if (total > cap) atomicOr(&flags[0], 2);
     }
-    const bool active = L >= 0 && k < cap;  // uniform within the half-wavefront
-    uint8_t* s_raw = s_patch + half * DP_WAVE_BYTES;
+    const bool active = L >= 0 && k < cap;  // uniform within the group
+    uint8_t* s_raw = s_patch + grp * DP_WAVE_BYTES;
     uint8_t* s_blr = s_raw + 31 * DP_RAW_PITCH;
     const LevelInfo lv = P.lv[active ? L : 0];
     int x = 0, y = 0, offr = 0, offb = 0;
@@ -834,37 +834,43 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         const int xr0 = (x - 15) & ~3;
         offr = (x - 15) - xr0;
         const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
-        stage_patch(img, lv.pitch, xr0, y - 15, 31, min(9, (lv.pitch - xr0) >> 2), s_raw, DP_RAW_PITCH, hl, al_raw);
+        stage_patch(img, lv.pitch, xr0, y - 15, 31, min(9, (lv.pitch - xr0) >> 2), s_raw, DP_RAW_PITCH, gl, al_raw);
         if (desc) {
             float inv = 1.f / lv.scale;
             int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
             const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
             const int xb0 = (cx - 19) & ~3;
             offb = (cx - 19) - xb0;
-            stage_patch(bl, lv.bpitch, xb0, cy - 19, 39, min(11, (lv.bpitch - xb0) >> 2), s_blr, DP_BLR_PITCH, hl, true);
+            stage_patch(bl, lv.bpitch, xb0, cy - 19, 39, min(11, (lv.bpitch - xb0) >> 2), s_blr, DP_BLR_PITCH, gl, true);
         }
     }
     __syncthreads();
-    // intensity centroid over the radius-15 disc: one row per lane (31 of the 32 lanes)
+    // intensity centroid over the radius-15 disc: rows gl and gl + 16 of the 31 on each lane
     int m10 = 0, m01 = 0;
-    if (active && hl < 31) {
-        int v = hl - 15;
-        int d = P.umax[v < 0 ? -v : v];
-        const uint8_t* row = s_raw + hl * DP_RAW_PITCH + 15 + offr;
-        int rs = 0;
-        for (int u = -d; u <= d; u++) {
-            int p = row[u];
-            m10 += u * p;
-            rs += p;
+    if (active) {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int row_i = gl + rr * DG;
+            if (row_i < 31) {
+                int v = row_i - 15;
+                int d = P.umax[v < 0 ? -v : v];
+                const uint8_t* row = s_raw + row_i * DP_RAW_PITCH + 15 + offr;
+                int rs = 0;
+                for (int u = -d; u <= d; u++) {
+                    int p = row[u];
+                    m10 += u * p;
+                    rs += p;
+                }
+                m01 += v * rs;
+            }
         }
-        m01 = v * rs;
     }
-    m10 = half_sum(m10);
-    m01 = half_sum(m01);
+    m10 = group_sum(m10);
+    m01 = group_sum(m01);
     if (!active) return;
     float angle = fast_atan2_deg((float)m01, (float)m10);
     mo_keypoint* o = kps + (size_t)frame * cap + k;
-    if (hl == 0) {
+    if (gl == 0) {
         o->x = px; o->y = py;
         o->size = 31 * lv.scale;
         o->angle = angle;
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         o->class_id = -1;
     }
     if (desc)  // patch-local centre (19 + offb, 19); bounds guaranteed by edge_threshold >= 19 and pattern radius <= 18
-        desc[((size_t)frame * cap + k) * 32 + hl] = rbrief_byte(s_blr, DP_BLR_PITCH, 19 + offb, 19, angle, hl);
+        *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) = rbrief_u16(s_blr, DP_BLR_PITCH, 19 + offb, 19, angle, gl);
 }
 
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
