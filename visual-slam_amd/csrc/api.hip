@@ -31,12 +31,13 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     if (d_desc) {
         hipStream_t main_s = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, main_s));
-        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-        c->stream = c->aux_stream;
-        if (c->timing) hipEventRecord(c->ev_aux0, c->aux_stream);
+        hipStream_t aux = c->serial_blur ? main_s : c->aux_stream;  // serial_blur: diagnostics (stand-alone stage times)
+        HIPCHK(c, hipStreamWaitEvent(aux, c->ev_fork, 0));
+        c->stream = aux;
+        if (c->timing) hipEventRecord(c->ev_aux0, aux);
         rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels);
-        if (c->timing) hipEventRecord(c->ev_aux1, c->aux_stream);
-        hipEventRecord(c->ev_join, c->aux_stream);
+        if (c->timing) hipEventRecord(c->ev_aux1, aux);
+        hipEventRecord(c->ev_join, aux);
         c->stream = main_s;
         if (rc) return rc;
     }

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <cstdlib>
+
 #include "common.h"
 
 int mo_fail(mo_ctx* c, int code, const std::string& msg) {
@@ -58,6 +60,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess)
             hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     }
+    if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] == '1';
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipEventCreate(&c->ev_aux0);

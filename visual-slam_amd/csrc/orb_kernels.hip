@@ -139,15 +139,24 @@ struct TileTab {
 };
 
 #define BT_W 64
-#define BT_H 16
+#define BT_H 26   // output rows per tile: 26 + 6 halo rows = 16 row pairs
 #define BT_PW 80  // LDS pixel-tile pitch: 4 (aligned lead-in) + 64 + 3 halo, rounded to a multiple of 16
+#define BT_ROWS (BT_H + 6)
 
-// 7x7 Gaussian (8-bit quantised taps, sum 257), separable through LDS: u8 tile -> u16 row sums -> u8 output.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
+// 7x7 Gaussian (8-bit quantised taps, sum 257), separable through LDS: u8 tile -> u16 row sums -> u8 output, all in
+// integer dot instructions.  Row pass: the 7 taps of one output are two v_dot4_u32_u8 on byte windows cut out of three
+// aligned dwords with v_alignbyte.  The u16 row sums of tile rows 2p and 2p+1 are stored interleaved in one dword per
+// column, so the column pass is four v_dot2_u32_u16 per output (tap pairs shifted by one row for odd output rows).
 // Interior tiles are staged with aligned dword loads; tiles touching the level border index with REFLECT_101.
 __global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* __restrict__ gray,
                                               const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_px[(BT_H + 6) * BT_PW];
-    __shared__ __attribute__((aligned(16))) uint16_t s_row[(BT_H + 6) * BT_W];
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[BT_ROWS * BT_PW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_row[(BT_ROWS / 2) * BT_W];  // [row pair][column] = lo: even row, hi: odd
     int tile = blockIdx.x, frame = blockIdx.y;
     int L = 0;
     while (L + 1 < T.nlevels && tile >= T.cum[L + 1]) L++;
@@ -160,67 +169,68 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* 
     const bool interior = tx0 >= 4 && ty0 >= 3 && tx0 + BT_W + 4 <= lv.w && ty0 + BT_H + 3 <= lv.h &&
                           (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
     if (interior) {
-        for (int i = tid; i < (BT_H + 6) * 18; i += 256) {
+        for (int i = tid; i < BT_ROWS * 18; i += 256) {
             int r = i / 18, c4 = i - r * 18;
             const uint32_t* src = (const uint32_t*)(img + (size_t)(ty0 + r - 3) * lv.pitch + tx0 - 4);
             ((uint32_t*)(s_px + r * BT_PW))[c4] = src[c4];
         }
     } else {
-        for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        for (int i = tid; i < BT_ROWS * (BT_W + 6); i += 256) {
             int r = i / (BT_W + 6), cidx = i - r * (BT_W + 6);
             int y = reflect101(ty0 + r - 3, lv.h), x = reflect101(tx0 + cidx - 3, lv.w);
             s_px[r * BT_PW + cidx + 1] = img[(size_t)y * lv.pitch + x];
         }
     }
     __syncthreads();
-    const int g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];
-    // row pass: one task = 4 adjacent outputs of one tile row, fed by three aligned dword reads (12 pixels)
-    for (int task = tid; task < (BT_H + 6) * 16; task += 256) {
-        const int r = task >> 4, q = task & 15;
-        const uint32_t* pw = (const uint32_t*)(s_px + r * BT_PW + 4 * q);
-        const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-        int px[12];
+    const uint32_t g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];
+    {   // row pass: one task = 4 adjacent outputs of tile rows 2p and 2p+1 (16 row pairs x 16 quads = 256 tasks)
+        const uint32_t ta = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), tb = g2 | (g1 << 8) | (g0 << 16);
+        const int p = tid >> 4, q = tid & 15;
+        uint32_t o[2][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            px[k] = (w0 >> (8 * k)) & 0xFF;
-            px[4 + k] = (w1 >> (8 * k)) & 0xFF;
-            px[8 + k] = (w2 >> (8 * k)) & 0xFF;
+        for (int h = 0; h < 2; h++) {
+            const uint32_t* pw = (const uint32_t*)(s_px + (2 * p + h) * BT_PW + 4 * q);
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+            // output column 4q+k is centred on s_px column 4q+k+4: taps over bytes k+1 .. k+7 of (w0, w1, w2)
+            o[h][0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tb, 0, false), false);
+            o[h][1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tb, 0, false), false);
+            o[h][2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tb, 0, false), false);
+            o[h][3] = __builtin_amdgcn_udot4(w1, ta, __builtin_amdgcn_udot4(w2, tb, 0, false), false);
         }
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {  // output column 4q+k is centred on s_px column 4q+k+4
-            const int* p = &px[k + 1];
-            o[k] = (uint32_t)(g0 * (p[0] + p[6]) + g1 * (p[1] + p[5]) + g2 * (p[2] + p[4]) + g3 * p[3]);  // <= 65535
-        }
-        uint2 packed;
-        packed.x = o[0] | (o[1] << 16);
-        packed.y = o[2] | (o[3] << 16);
-        *(uint2*)(&s_row[r * BT_W + 4 * q]) = packed;
+        uint4 packed;  // each sum <= 257 * 255 = 65535
+        packed.x = o[0][0] | (o[1][0] << 16);
+        packed.y = o[0][1] | (o[1][1] << 16);
+        packed.z = o[0][2] | (o[1][2] << 16);
+        packed.w = o[0][3] | (o[1][3] << 16);
+        *(uint4*)(&s_row[p * BT_W + 4 * q]) = packed;
     }
     __syncthreads();
-    // column pass: each thread 4 adjacent columns of one row (seven 8-byte LDS reads) -> one dword store
-    {
-        const int r = tid >> 4, c0 = (tid & 15) * 4;
-        const int x = tx0 + c0, y = ty0 + r;
-        if (y < lv.h && x < lv.w) {
-            uint2 rowv[7];
+    {   // column pass: each thread 4 adjacent columns of output rows 2p and 2p+1, from row pairs p .. p+3
+        const int p = tid >> 4, c0 = (tid & 15) * 4;
+        const int x = tx0 + c0, y = ty0 + 2 * p;
+        if (p < BT_H / 2 && y < lv.h && x < lv.w) {
+            // even output row 2p   : rows 2p .. 2p+6   = pairs (g0,g1) (g2,g3) (g2,g1) (g0, 0)
+            // odd  output row 2p+1 : rows 2p+1 .. 2p+7 = pairs ( 0,g0) (g1,g2) (g3,g2) (g1,g0)
+            const uint32_t e0 = g0 | (g1 << 16), e1 = g2 | (g3 << 16), e2 = g2 | (g1 << 16), e3 = g0;
+            const uint32_t d0 = g0 << 16, d1 = g1 | (g2 << 16), d2 = g3 | (g2 << 16), d3 = g1 | (g0 << 16);
+            uint4 v[4];
 #pragma unroll
-            for (int j = 0; j < 7; j++) rowv[j] = *(const uint2*)(&s_row[(r + j) * BT_W + c0]);
-            uint32_t packed = 0;
+            for (int j = 0; j < 4; j++) v[j] = *(const uint4*)(&s_row[(p + j) * BT_W + c0]);
+            uint32_t pe = 0, po = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                int e[7];
-#pragma unroll
-                for (int j = 0; j < 7; j++) {
-                    uint32_t wv = (k < 2) ? rowv[j].x : rowv[j].y;
-                    e[j] = (wv >> (16 * (k & 1))) & 0xFFFF;
-                }
-                int acc = g0 * (e[0] + e[6]) + g1 * (e[1] + e[5]) + g2 * (e[2] + e[4]) + g3 * e[3];
-                int v = min((acc + (1 << 15)) >> 16, 255);
-                packed |= (uint32_t)v << (8 * k);
+                const uint32_t a0 = k == 0 ? v[0].x : k == 1 ? v[0].y : k == 2 ? v[0].z : v[0].w;
+                const uint32_t a1 = k == 0 ? v[1].x : k == 1 ? v[1].y : k == 2 ? v[1].z : v[1].w;
+                const uint32_t a2 = k == 0 ? v[2].x : k == 1 ? v[2].y : k == 2 ? v[2].z : v[2].w;
+                const uint32_t a3 = k == 0 ? v[3].x : k == 1 ? v[3].y : k == 2 ? v[3].z : v[3].w;
+                uint32_t se = udot2(a0, e0, udot2(a1, e1, udot2(a2, e2, udot2(a3, e3, 1u << 15))));
+                uint32_t so = udot2(a0, d0, udot2(a1, d1, udot2(a2, d2, udot2(a3, d3, 1u << 15))));
+                pe |= min(se >> 16, 255u) << (8 * k);
+                po |= min(so >> 16, 255u) << (8 * k);
             }
             uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff + (size_t)y * lv.bpitch + x;
-            *(uint32_t*)out = packed;  // bpitch is a multiple of 16 >= w: the <= 3 bytes past w land in row padding
+            *(uint32_t*)out = pe;  // bpitch is a multiple of 16 >= w: the <= 3 bytes past w land in row padding
+            if (y + 1 < lv.h) *(uint32_t*)(out + lv.bpitch) = po;
         }
     }
 }
