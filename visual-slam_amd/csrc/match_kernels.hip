@@ -16,10 +16,9 @@
 #define MQ_PER_BLOCK (MQ_THREADS * MQ_Q)
 #define KEY_NONE 0xFFFFFFFFu
 
-__device__ __forceinline__ void emit_match(uint32_t k0, uint32_t k1, double ratio, size_t o, int32_t* oidx, int32_t* odist,
+// one output row: i0/i1 = trainIdx of the best / second-best neighbour (-1: none), d0/d1 their distances
+__device__ __forceinline__ void emit_match(int i0, int d0, int i1, int d1, double ratio, size_t o, int32_t* oidx, int32_t* odist,
                                            uint8_t* opass) {
-    int i0 = k0 == KEY_NONE ? -1 : (int)(k0 & 0xFFFFFu), i1 = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFFu);
-    int d0 = k0 == KEY_NONE ? INT_MAX : (int)(k0 >> 20), d1 = k1 == KEY_NONE ? INT_MAX : (int)(k1 >> 20);
     oidx[2 * o] = i0; oidx[2 * o + 1] = i1;
     odist[2 * o] = d0; odist[2 * o + 1] = d1;
     // matcher.py:73-81: len(match) >= 2 -> m.distance < ratio * n.distance (Python floats = IEEE double);
@@ -29,6 +28,13 @@ __device__ __forceinline__ void emit_match(uint32_t k0, uint32_t k1, double rati
     else if (i1 < 0 || !(ratio > 0.0)) pass = 1;
     else pass = ((double)d0 < ratio * (double)d1) ? 1 : 0;
     opass[o] = pass;
+}
+
+__device__ __forceinline__ void emit_match_key(uint32_t k0, uint32_t k1, double ratio, size_t o, int32_t* oidx, int32_t* odist,
+                                               uint8_t* opass) {
+    int i0 = k0 == KEY_NONE ? -1 : (int)(k0 & 0xFFFFFu), i1 = k1 == KEY_NONE ? -1 : (int)(k1 & 0xFFFFFu);
+    int d0 = k0 == KEY_NONE ? INT_MAX : (int)(k0 >> 20), d1 = k1 == KEY_NONE ? INT_MAX : (int)(k1 >> 20);
+    emit_match(i0, d0, i1, d1, ratio, o, oidx, odist, opass);
 }
 
 __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict__ qbase, const uint8_t* __restrict__ tbase,
@@ -75,7 +81,149 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
 #pragma unroll
     for (int m = 0; m < MQ_Q; m++) {
         const int qi = blockIdx.x * MQ_PER_BLOCK + m * MQ_THREADS + threadIdx.x;
-        if (qi < nq) emit_match(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
+        if (qi < nq) emit_match_key(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix-core path.  The 2000 x 2000 x 256-bit distance table of a pair is a GEMM over +-1 vectors: with every
+// descriptor bit expanded to the int8 value +127 (set) or -127 (clear), a.b = 16129 * (256 - 2 * hamming).  The
+// accumulator of v_mfma_i32_32x32x32_i8 is started at C = 31 - (train row within the tile), so each of its 16 registers
+// ends as  M - (32258 * hamming + row)  with M = 16129 * 256 + 31: ONE signed integer ordered exactly like
+// (distance, trainIdx) reversed.  The epilogue therefore only keeps the two largest of a lane's 16 registers
+// (v_max / v_med3), turns them into ascending keys 32258 * hamming + trainIdx and merges them into the running pair;
+// no per-element key has to be built.  The MFMA result layout puts the query on the lane (column) and 16 train rows in
+// the registers, so the scan is lane-local until the two half-wavefronts of a column are merged at the very end.
+//
+// Train rows are expanded from bits to bytes by the workgroup itself (one dword of bits per thread and tile) into a
+// double-buffered LDS tile (row pitch 272 B: the 16-byte fragment reads of 16 lanes hit 64 distinct banks); the query
+// fragments are expanded once into registers.  The k order inside a fragment is the same for both operands (byte
+// position = bit index), which is all a dot product needs.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define MM_THREADS 256
+#define MM_QPB 256        // queries per workgroup: two 32-column MFMA blocks per wavefront
+#define MM_TT 32          // train rows per tile
+#define MM_PITCH 272
+#define MM_C 32258        // ascending key = MM_C * hamming + trainIdx
+#define MM_M (16129 * 256 + 31)
+#define MM_MAX_TRAIN 32258
+#define MM_NONE 0x7FFFFFFF
+
+__device__ __forceinline__ uint32_t expand4(uint32_t nib) {  // 4 bits -> 4 bytes: set -> +127 (0x7F), clear -> -127 (0x81)
+    return 0x81818181u - ((nib * 0x00408102u) & 0x02020202u);
+}
+__device__ __forceinline__ v4i expand16(uint32_t hw) {
+    v4i r;
+    r.x = (int)expand4(hw & 15u); r.y = (int)expand4((hw >> 4) & 15u);
+    r.z = (int)expand4((hw >> 8) & 15u); r.w = (int)expand4((hw >> 12) & 15u);
+    return r;
+}
+
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {  // the compiler only forms v_med3_i32 for constant clamps
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// two largest of the 16 accumulator registers -> ascending keys -> merged into the running (k0 <= k1)
+__device__ __forceinline__ void fold_tile(const v16i& acc, int mtb, int& k0, int& k1) {
+    int m0 = max(acc[0], acc[1]), m1 = min(acc[0], acc[1]);
+#pragma unroll
+    for (int k = 2; k < 16; k++) {  // m0 >= m1: the second largest of {m0, m1, x} is their median
+        m1 = med3_i32(m0, m1, acc[k]);
+        m0 = max(m0, acc[k]);
+    }
+    const int v0 = mtb - m0, v1 = mtb - m1;  // v0 <= v1
+    k1 = min(min(k1, v1), max(k0, v0));
+    k0 = min(k0, v0);
+}
+
+__global__ __launch_bounds__(MM_THREADS) void k_match_mfma(const uint8_t* __restrict__ qbase, const uint8_t* __restrict__ tbase,
+                                                           size_t q_stride, size_t t_stride, const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ qf, const int32_t* __restrict__ tf,
+                                                           int nq_fixed, int nt_fixed, int out_stride, double ratio,
+                                                           int32_t* __restrict__ oidx, int32_t* __restrict__ odist,
+                                                           uint8_t* __restrict__ opass) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_t[2][MM_TT * MM_PITCH];
+    const int pair = blockIdx.y;
+    const int qfr = qf ? qf[pair] : pair, tfr = tf ? tf[pair] : pair;
+    const int nq = counts ? min(counts[qfr], out_stride) : nq_fixed;
+    const int nt = counts ? min(counts[tfr], out_stride) : nt_fixed;
+    if (blockIdx.x * MM_QPB >= nq) return;  // uniform over the workgroup
+    const uint32_t* q = (const uint32_t*)(qbase + (size_t)qfr * q_stride);
+    const uint32_t* t = (const uint32_t*)(tbase + (size_t)tfr * t_stride);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hh = lane >> 5;
+    const int qblock = blockIdx.x * MM_QPB + wv * 64;
+
+    v4i bq[2][8];  // query fragments: lane (col, hh), k-step s <- bits 32 s + 16 hh .. + 15 of query col
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int qi = min(qblock + b * 32 + col, nq - 1);
+#pragma unroll
+        for (int s = 0; s < 8; s++) bq[b][s] = expand16((q[(size_t)qi * 8 + s] >> (16 * hh)) & 0xFFFFu);
+    }
+    v16i cinit;
+#pragma unroll
+    for (int k = 0; k < 16; k++) cinit[k] = 31 - ((k & 3) + 8 * (k >> 2) + 4 * hh);
+    int k0[2] = {MM_NONE, MM_NONE}, k1[2] = {MM_NONE, MM_NONE};
+
+    const int ntiles = (nt + MM_TT - 1) / MM_TT;
+    const int trow = tid >> 3, td = tid & 7;  // staging: one dword of train bits per thread and tile
+    if (ntiles > 0) {
+        {
+            const uint32_t w = trow < nt ? t[(size_t)trow * 8 + td] : 0u;
+            uint8_t* dst = s_t[0] + trow * MM_PITCH + td * 32;
+            *(v4i*)dst = expand16(w & 0xFFFFu);
+            *(v4i*)(dst + 16) = expand16(w >> 16);
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < ntiles; j++) {
+        uint32_t nw = 0;
+        const bool more = j + 1 < ntiles;
+        if (more) {
+            const int r = (j + 1) * MM_TT + trow;
+            nw = r < nt ? t[(size_t)r * 8 + td] : 0u;
+        }
+        const uint8_t* frag = s_t[j & 1] + col * MM_PITCH + hh * 16;
+        v16i acc0 = cinit, acc1 = cinit;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const v4i a = *(const v4i*)(frag + s * 32);
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[0][s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[1][s], acc1, 0, 0, 0);
+        }
+        if (j == ntiles - 1 && (nt & (MM_TT - 1))) {  // rows past the last train descriptor never win
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (j * MM_TT + (k & 3) + 8 * (k >> 2) + 4 * hh >= nt) { acc0[k] = -(1 << 30); acc1[k] = -(1 << 30); }
+        }
+        const int mtb = MM_M + j * MM_TT;
+        fold_tile(acc0, mtb, k0[0], k1[0]);
+        fold_tile(acc1, mtb, k0[1], k1[1]);
+        if (more) {
+            uint8_t* dst = s_t[(j + 1) & 1] + trow * MM_PITCH + td * 32;
+            *(v4i*)dst = expand16(nw & 0xFFFFu);
+            *(v4i*)(dst + 16) = expand16(nw >> 16);
+        }
+        __syncthreads();
+    }
+    // the two half-wavefronts of a column hold disjoint train rows: merge, then half hh writes query block hh
+    int r0 = MM_NONE, r1 = MM_NONE;
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const int o0 = __shfl_xor(k0[b], 32, 64), o1 = __shfl_xor(k1[b], 32, 64);
+        const int n1 = min(min(k1[b], o1), max(k0[b], o0)), n0 = min(k0[b], o0);
+        if (b == hh) { r0 = n0; r1 = n1; }
+    }
+    const int qi = qblock + hh * 32 + col;
+    if (qi < nq) {
+        const bool h0 = r0 < MM_C * 257, h1 = r1 < MM_C * 257;
+        const int d0 = r0 / MM_C, d1 = r1 / MM_C;
+        emit_match(h0 ? r0 - d0 * MM_C : -1, h0 ? d0 : INT_MAX, h1 ? r1 - d1 * MM_C : -1, h1 ? d1 : INT_MAX, ratio,
+                   (size_t)pair * out_stride + qi, oidx, odist, opass);
     }
 }
 
@@ -86,6 +234,14 @@ int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t
     int nq_max = d_counts ? out_stride : nq_fixed;
     if (nq_max <= 0) return MO_OK;
     if ((d_counts ? out_stride : nt_fixed) >= (1 << 20)) return mo_fail(c, MO_ERR_UNSUPPORTED, "more than 2^20-1 train descriptors");
+    const int nt_max = d_counts ? out_stride : nt_fixed;
+    if (nt_max <= MM_MAX_TRAIN && !c->match_valu) {
+        dim3 grid((nq_max + MM_QPB - 1) / MM_QPB, n_pairs);
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(MM_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf,
+                           d_tf, nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
+        HIPCHK(c, hipGetLastError());
+        return MO_OK;
+    }
     dim3 grid((nq_max + MQ_PER_BLOCK - 1) / MQ_PER_BLOCK, n_pairs);
     hipLaunchKernelGGL(k_match, grid, dim3(MQ_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf, d_tf,
                        nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
