@@ -127,6 +127,13 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {  // the compiler 
     return r;
 }
 
+// 32 train bits -> 32 bytes of the LDS tile through the byte table (4 lookups instead of 32 vector instructions)
+__device__ __forceinline__ void stage_train(uint8_t* dst, uint32_t w, const uint2* lut) {
+    const uint2 e0 = lut[w & 255u], e1 = lut[(w >> 8) & 255u], e2 = lut[(w >> 16) & 255u], e3 = lut[w >> 24];
+    *(uint4*)dst = make_uint4(e0.x, e0.y, e1.x, e1.y);
+    *(uint4*)(dst + 16) = make_uint4(e2.x, e2.y, e3.x, e3.y);
+}
+
 // two largest of the 16 accumulator registers -> ascending keys -> merged into the running (k0 <= k1)
 __device__ __forceinline__ void fold_tile(const v16i& acc, int mtb, int& k0, int& k1) {
     int m0 = max(acc[0], acc[1]), m1 = min(acc[0], acc[1]);
@@ -147,11 +154,14 @@ __global__ __launch_bounds__(MM_THREADS) void k_match_mfma(const uint8_t* __rest
                                                            int32_t* __restrict__ oidx, int32_t* __restrict__ odist,
                                                            uint8_t* __restrict__ opass) {
     __shared__ __attribute__((aligned(16))) uint8_t s_t[2][MM_TT * MM_PITCH];
+    __shared__ uint2 s_lut[256];  // 8 bits -> 8 bytes of +-127
     const int pair = blockIdx.y;
     const int qfr = qf ? qf[pair] : pair, tfr = tf ? tf[pair] : pair;
     const int nq = counts ? min(counts[qfr], out_stride) : nq_fixed;
     const int nt = counts ? min(counts[tfr], out_stride) : nt_fixed;
     if (blockIdx.x * MM_QPB >= nq) return;  // uniform over the workgroup
+    s_lut[threadIdx.x] = make_uint2(expand4(threadIdx.x & 15u), expand4(threadIdx.x >> 4));
+    __syncthreads();
     const uint32_t* q = (const uint32_t*)(qbase + (size_t)qfr * q_stride);
     const uint32_t* t = (const uint32_t*)(tbase + (size_t)tfr * t_stride);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, hh = lane >> 5;
@@ -174,9 +184,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_match_mfma(const uint8_t* __rest
     if (ntiles > 0) {
         {
             const uint32_t w = trow < nt ? t[(size_t)trow * 8 + td] : 0u;
-            uint8_t* dst = s_t[0] + trow * MM_PITCH + td * 32;
-            *(v4i*)dst = expand16(w & 0xFFFFu);
-            *(v4i*)(dst + 16) = expand16(w >> 16);
+            stage_train(s_t[0] + trow * MM_PITCH + td * 32, w, s_lut);
         }
         __syncthreads();
     }
@@ -204,9 +212,7 @@ __global__ __launch_bounds__(MM_THREADS) void k_match_mfma(const uint8_t* __rest
         fold_tile(acc0, mtb, k0[0], k1[0]);
         fold_tile(acc1, mtb, k0[1], k1[1]);
         if (more) {
-            uint8_t* dst = s_t[(j + 1) & 1] + trow * MM_PITCH + td * 32;
-            *(v4i*)dst = expand16(nw & 0xFFFFu);
-            *(v4i*)(dst + 16) = expand16(nw >> 16);
+            stage_train(s_t[(j + 1) & 1] + trow * MM_PITCH + td * 32, nw, s_lut);
         }
         __syncthreads();
     }
