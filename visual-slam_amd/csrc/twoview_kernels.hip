@@ -8,17 +8,18 @@
 // on hypothesis-level equality with cv2.
 //
 //   k_tv_prep    per pair: gather the ratio-test survivors (query order) -> normalised f64 correspondences
-//   k_tv_hyp     one thread per hypothesis: counter-based 8-sample, 8x9 null vector by full-pivot Gauss-Jordan,
-//                projection on the essential manifold (3x3 SVD via Jacobi), Sampson inlier count over all
-//                correspondences staged in LDS; block max -> one atomicMax per block
-//   k_tv_finish  one block per pair: consensus set of the best hypothesis -> least-squares 8-point refit
-//                (9x9 normal matrix, Jacobi) -> final inliers -> decompose E -> cheirality vote over the 4
-//                (R, t) candidates with per-point DLT -> final DLT triangulation in pixel space
+//   k_tv_hyp     one thread per hypothesis: counter-based 8-sample, 8x9 null vector by Householder QR (registers),
+//                projection on the essential manifold (3x3 SVD via Jacobi), MSAC cost (truncated Sampson distance)
+//                over all correspondences, which arrive as scalar operands; block min -> one atomicMin per block
+//   k_tv_finish  one block per pair: consensus set of the best hypothesis -> adaptive-threshold least-squares
+//                8-point refits (9x9 normal matrix, inverse iteration) -> final inliers -> decompose E -> cheirality
+//                vote over the 4 (R, t) candidates with per-point DLT -> final DLT triangulation in pixel space
 #include <cmath>
 
 #include "common.h"
 
 #define TV_BLOCK 256
+#define TVF_BLOCK 512  // k_tv_finish: one block per pair, about one correspondence per thread in the per-point phases
 
 struct TvWork {
     double* xn;        // [pairs][cap][4] normalised x1,y1,x2,y2
@@ -409,10 +410,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
 }
 
 // ---------------------------------------------------------------- hypotheses ----------------------
-#define TV_CHUNK 1024  // correspondences staged in LDS per pass (32 KB)
 
 __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
-    __shared__ double s_pts[TV_CHUNK * 4];
     __shared__ unsigned long long s_best[TV_BLOCK / 64];
     const int pair = blockIdx.y, tid = threadIdx.x;
     const int h = blockIdx.x * TV_BLOCK + tid;
@@ -438,17 +437,16 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
     }
     // MSAC score: sum of Sampson distances truncated at thr^2 (a pure inlier count prefers slightly perturbed
     // models that catch more chance inliers).  Compared as float32, ties -> lowest hypothesis index.
+    // The correspondences are the same for every lane: they arrive through wave-uniform scalar loads (constant address
+    // space; k_tv_prep wrote them in an earlier launch) and feed the fp64 FMAs as scalar operands, one per instruction.
     double cost = 0.0;
-    for (int base = 0; base < m; base += TV_CHUNK) {
-        int n = min(TV_CHUNK, m - base);
-        __syncthreads();
-        for (int i = tid; i < n * 4; i += TV_BLOCK) s_pts[i] = xn[(size_t)base * 4 + i];
-        __syncthreads();
-        if (valid) {
-            for (int i = 0; i < n; i++) {
-                double err = sampson_fast(E, s_pts[4 * i], s_pts[4 * i + 1], s_pts[4 * i + 2], s_pts[4 * i + 3]);
-                cost += fmin(err, thr2);
-            }
+    if (valid) {
+        typedef const __attribute__((address_space(4))) double* cdp;
+        const cdp pts = (cdp)(uintptr_t)xn;
+#pragma unroll 4
+        for (int i = 0; i < m; i++) {
+            double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
+            cost += fmin(err, thr2);
         }
     }
     unsigned long long key = ~0ull;
@@ -490,7 +488,7 @@ __device__ inline double block_sum(double v, double* s_red) {
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     double r = 0;
-    for (int k = 0; k < TV_BLOCK / 64; k++) r += s_red[k];
+    for (int k = 0; k < TVF_BLOCK / 64; k++) r += s_red[k];
     return r;
 }
 
@@ -500,13 +498,13 @@ __device__ inline int block_sum_i(int v, int* s_red) {
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     int r = 0;
-    for (int k = 0; k < TV_BLOCK / 64; k++) r += s_red[k];
+    for (int k = 0; k < TVF_BLOCK / 64; k++) r += s_red[k];
     return r;
 }
 
-__global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w) {
-    __shared__ double s_red[TV_BLOCK / 64];
-    __shared__ int s_redi[TV_BLOCK / 64];
+__global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w) {
+    __shared__ double s_red[TVF_BLOCK / 64];
+    __shared__ int s_redi[TVF_BLOCK / 64];
     __shared__ double s_E[9];
     __shared__ double s_P[4][12];   // candidate [R|t] in normalised coordinates
     __shared__ double s_Ppix[2][12];
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     uint8_t* ran_out = a.d_ransac ? a.d_ransac + (size_t)pair * a.cap : nullptr;
     const int out_n = a.d_p1 ? a.m_fixed : a.cap;
     const float qnan = __uint_as_float(0x7FC00000u);
-    for (int i = tid; i < out_n; i += TV_BLOCK) {
+    for (int i = tid; i < out_n; i += TVF_BLOCK) {
         Xout[3 * i] = qnan; Xout[3 * i + 1] = qnan; Xout[3 * i + 2] = qnan;
         if (inl_out) inl_out[i] = 0;
         if (ran_out) ran_out[i] = 0;
@@ -547,7 +545,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     // residual of the previous selection, clamped to [thr/64, thr], so chance inliers of the loose RANSAC threshold
     // do not bias the algebraic fit; a refit is only accepted while >= half of the original consensus is selected.
     __shared__ double s_N[45];
-    __shared__ double s_part[TV_BLOCK / 64][45];
+    __shared__ double s_part[TVF_BLOCK / 64][45];
     __shared__ int s_stop;
     const double lo2 = thr2 / 4096.0;
     int n0;
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         for (int j = 0; j < 9; j++) E[j] = s_E[j];
         int cnt = 0;
         double sd = 0;
-        for (int i = tid; i < m; i += TV_BLOCK) {
+        for (int i = tid; i < m; i += TVF_BLOCK) {
             double d = sampson(E, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]);
             if (d <= thr2) { cnt++; sd += d; }
         }
@@ -584,7 +582,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
         {
             double E[9];
             for (int j = 0; j < 9; j++) E[j] = s_E[j];
-            for (int i = tid; i < m; i += TV_BLOCK) {
+            for (int i = tid; i < m; i += TVF_BLOCK) {
                 double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
                 double d = sampson(E, x1, y1, x2, y2);
                 if (d <= tau2) {
@@ -613,7 +611,11 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
             if ((tid & 63) == 0) s_part[tid >> 6][j] = v;
         }
         __syncthreads();
-        if (tid < 45) s_N[tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+        if (tid < 45) {
+            double v = 0;
+            for (int k = 0; k < TVF_BLOCK / 64; k++) v += s_part[k][tid];
+            s_N[tid] = v;
+        }
         __syncthreads();
         if (tid == 0) {  // smallest eigenvector of the normal matrix, seeded with the current estimate
             double E[9], Nn[45], en = 0;
@@ -671,11 +673,11 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     const double dist = 50.0;
     int good[4] = {0, 0, 0, 0};
-    unsigned char cmask[(2048 + TV_BLOCK - 1) / TV_BLOCK * 2];  // per-thread bits for up to 4096 points
+    unsigned char cmask[(2048 + TVF_BLOCK - 1) / TVF_BLOCK * 2];  // per-thread bits for up to 4096 points
     double E[9];
     for (int j = 0; j < 9; j++) E[j] = s_E[j];
     int slot = 0;
-    for (int i = tid; i < m; i += TV_BLOCK, slot++) {
+    for (int i = tid; i < m; i += TVF_BLOCK, slot++) {
         double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
         unsigned bits = 0;
         if (sampson(E, x1, y1, x2, y2) <= thr2) {
@@ -726,7 +728,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w)
     double Pa[12], Pb[12];
     for (int j = 0; j < 12; j++) { Pa[j] = s_Ppix[0][j]; Pb[j] = s_Ppix[1][j]; }
     slot = 0;
-    for (int i = tid; i < m; i += TV_BLOCK, slot++) {
+    for (int i = tid; i < m; i += TVF_BLOCK, slot++) {
         unsigned bits = slot < (int)sizeof(cmask) ? cmask[slot] : 0;
         if (!((bits >> win) & 1u)) continue;
         double X[4];
@@ -767,7 +769,7 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
     TvWork w = carve(c->d_tv, a.n_pairs, a.cap, a.n_hyp);
     hipLaunchKernelGGL(k_tv_prep, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
-    hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+    hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
