@@ -98,55 +98,22 @@ template <int N> __device__ void jacobi_eig(double* a, double* v) {
     }
 }
 
-// 9x9 symmetric eigen-decomposition by cyclic Jacobi with the matrix in LDS and one lane per row/column
-// (lanes 0..8 of one wavefront; every lane of that wavefront must call).  a, v: volatile LDS [81].
-__device__ void jacobi9_lanes(volatile double* a, volatile double* v, int lane) {
-    const int k = lane < 9 ? lane : 0;
-    if (lane < 9)
-        for (int j = 0; j < 9; j++) v[lane * 9 + j] = lane == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; sweep++) {
-        double off = 0, diag = 0;
-        if (lane < 9)
-            for (int j = 0; j < 9; j++) {
-                double x = a[lane * 9 + j];
-                if (j != lane) off += x * x; else diag += x * x;
-            }
-        for (int o = 8; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); diag += __shfl_xor(diag, o, 64); }
-        off = __shfl(off, 0, 64); diag = __shfl(diag, 0, 64);
-        if (off <= 1e-30 * diag || off == 0.0) break;
-        for (int p = 0; p < 8; p++)
-            for (int q = p + 1; q < 9; q++) {
-                double apq = a[p * 9 + q];
-                if (apq == 0.0) continue;  // wave-uniform
-                double theta = (a[q * 9 + q] - a[p * 9 + p]) / (2.0 * apq);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                double akp = a[k * 9 + p], akq = a[k * 9 + q];
-                if (lane < 9) { a[k * 9 + p] = c * akp - s * akq; a[k * 9 + q] = s * akp + c * akq; }
-                double apk = a[p * 9 + k], aqk = a[q * 9 + k];
-                if (lane < 9) { a[p * 9 + k] = c * apk - s * aqk; a[q * 9 + k] = s * apk + c * aqk; }
-                double vkp = v[k * 9 + p], vkq = v[k * 9 + q];
-                if (lane < 9) { v[k * 9 + p] = c * vkp - s * vkq; v[k * 9 + q] = s * vkp + c * vkq; }
-            }
-    }
-}
-
-// Smallest eigenvector of the 9x9 normal matrix N (45 upper-triangular sums, row-major order p <= q) by inverse
-// iteration on N + delta*I with an LDL^T factorisation; x holds the starting vector (the current estimate, already
-// close) and receives the result.  All indices are compile-time constants (registers).  Converges at the rate
-// lambda_9 / lambda_8 per step: a couple of steps on clean data, more on noisy data -> fixed 16 steps with an
-// early exit once the direction stops moving.
-__device__ void smallest_eigvec9(const double* Nsym, double* x) {
-    double L[9][9], D[9];
+// Smallest eigenvector of a symmetric positive semi-definite NxN matrix (upper triangle packed row-major, p <= q) by
+// inverse iteration on M + delta*I with an LDL^T factorisation; x holds the starting vector (unit length) and receives
+// the result.  All indices are compile-time constants (registers).  Converges at the rate lambda_min / lambda_next per
+// step: a couple of steps on clean data, more on noisy data -> at most max_it steps with an early exit once the
+// iterate stops moving (|y - x|^2 < 1e-28, measured on the difference so rounding in a dot product cannot hide it).
+template <int N> __device__ void smallest_eigvec(const double* Msym, double* x, int max_it) {
+    double L[N][N], D[N];
     double tr = 0;
 #pragma unroll
-    for (int p = 0, k = 0; p < 9; p++)
+    for (int p = 0, k = 0; p < N; p++)
 #pragma unroll
-        for (int q = p; q < 9; q++, k++) { L[q][p] = Nsym[k]; if (p == q) tr += Nsym[k]; }
+        for (int q = p; q < N; q++, k++) { L[q][p] = Msym[k]; if (p == q) tr += Msym[k]; }
     const double delta = 1e-15 * tr + 1e-300;
-    // LDL^T in place: L[i][j] (i > j) unit lower factor, D diagonal
+    // LDL^T in place: L[i][j] (i > j) unit lower factor, D diagonal (stored inverted)
 #pragma unroll
-    for (int j = 0; j < 9; j++) {
+    for (int j = 0; j < N; j++) {
         double d = L[j][j] + delta;
 #pragma unroll
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
@@ -154,36 +121,43 @@ __device__ void smallest_eigvec9(const double* Nsym, double* x) {
         D[j] = d;
         const double inv = 1.0 / d;
 #pragma unroll
-        for (int i = j + 1; i < 9; i++) {
+        for (int i = j + 1; i < N; i++) {
             double v = L[i][j];
 #pragma unroll
             for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
             L[i][j] = v * inv;
         }
     }
-    double y[9];
-    for (int it = 0; it < 16; it++) {
+    double Dinv[N];
 #pragma unroll
-        for (int i = 0; i < 9; i++) y[i] = x[i];
+    for (int i = 0; i < N; i++) Dinv[i] = 1.0 / D[i];
+    double y[N];
+    for (int it = 0; it < max_it; it++) {
 #pragma unroll
-        for (int i = 0; i < 9; i++)
+        for (int i = 0; i < N; i++) y[i] = x[i];
+#pragma unroll
+        for (int i = 0; i < N; i++)
 #pragma unroll
             for (int k = 0; k < i; k++) y[i] -= L[i][k] * y[k];
 #pragma unroll
-        for (int i = 0; i < 9; i++) y[i] /= D[i];
+        for (int i = 0; i < N; i++) y[i] *= Dinv[i];
 #pragma unroll
-        for (int i = 8; i >= 0; i--)
+        for (int i = N - 1; i >= 0; i--)
 #pragma unroll
-            for (int k = i + 1; k < 9; k++) y[i] -= L[k][i] * y[k];
+            for (int k = i + 1; k < N; k++) y[i] -= L[k][i] * y[k];
         double nn = 0, dot = 0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) nn += y[i] * y[i];
-        nn = 1.0 / sqrt(nn);
+        for (int i = 0; i < N; i++) { nn += y[i] * y[i]; dot += y[i] * x[i]; }
+        nn = (dot < 0 ? -1.0 : 1.0) / sqrt(nn);  // keep the orientation of the previous iterate
+        double d2 = 0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) { y[i] *= nn; dot += y[i] * x[i]; }
-#pragma unroll
-        for (int i = 0; i < 9; i++) x[i] = y[i];
-        if (fabs(dot) > 1.0 - 1e-15) break;  // x was unit length: direction converged
+        for (int i = 0; i < N; i++) {
+            y[i] *= nn;
+            const double d = y[i] - x[i];
+            d2 += d * d;
+            x[i] = y[i];
+        }
+        if (d2 < 1e-28) break;
     }
 }
 
@@ -464,22 +438,24 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
 }
 
 // ---------------------------------------------------------------- finish --------------------------
-// DLT null vector of the 4x4 system [x*P3-P1; y*P3-P2] for two views (smallest eigenvector of A^T A)
+// DLT null vector of the 4x4 system [x*P3-P1; y*P3-P2] for two views: smallest eigenvector of A^T A by inverse
+// iteration (the matrix is rank 3 up to noise, so two or three steps reach machine precision)
 __device__ void dlt_point(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double* X) {
     double A[16];
+#pragma unroll
     for (int k = 0; k < 4; k++) {
         A[0 * 4 + k] = x1 * P1[8 + k] - P1[k];
         A[1 * 4 + k] = y1 * P1[8 + k] - P1[4 + k];
         A[2 * 4 + k] = x2 * P2[8 + k] - P2[k];
         A[3 * 4 + k] = y2 * P2[8 + k] - P2[4 + k];
     }
-    double S[16], V[16];
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) S[i * 4 + j] = A[i] * A[j] + A[4 + i] * A[4 + j] + A[8 + i] * A[8 + j] + A[12 + i] * A[12 + j];
-    jacobi_eig<4>(S, V);
-    int mn = 0;
-    for (int i = 1; i < 4; i++) if (S[i * 4 + i] < S[mn * 4 + mn]) mn = i;
-    for (int i = 0; i < 4; i++) X[i] = V[i * 4 + mn];
+    double S[10];
+#pragma unroll
+    for (int i = 0, k = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i; j < 4; j++, k++) S[k] = A[i] * A[j] + A[4 + i] * A[4 + j] + A[8 + i] * A[8 + j] + A[12 + i] * A[12 + j];
+    X[0] = 0.5; X[1] = 0.5; X[2] = 0.5; X[3] = 0.5;
+    smallest_eigvec<4>(S, X, 8);
 }
 
 __device__ inline double block_sum(double v, double* s_red) {
@@ -623,7 +599,7 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
             for (int i = 0; i < 9; i++) { E[i] = s_E[i]; en += E[i] * E[i]; }
             en = 1.0 / sqrt(en);
             for (int i = 0; i < 9; i++) E[i] *= en;
-            smallest_eigvec9(Nn, E);
+            smallest_eigvec<9>(Nn, E, 16);
             bool ok = project_essential(E);
             if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
             s_stop = ok ? 0 : 1;
