@@ -19,6 +19,7 @@
 #include "common.h"
 
 #define TV_BLOCK 256
+typedef double v4d __attribute__((ext_vector_type(4)));
 #define TVF_BLOCK 512  // k_tv_finish: one block per pair, about one correspondence per thread in the per-point phases
 
 struct TvWork {
@@ -521,7 +522,8 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     // residual of the previous selection, clamped to [thr/64, thr], so chance inliers of the loose RANSAC threshold
     // do not bias the algebraic fit; a refit is only accepted while >= half of the original consensus is selected.
     __shared__ double s_N[45];
-    __shared__ double s_part[TVF_BLOCK / 64][45];
+    __shared__ double s_R[TVF_BLOCK * 9];          // constraint rows of one pass
+    __shared__ double s_tile[TVF_BLOCK / 64][256];  // per-wavefront partial Gram tiles
     __shared__ int s_stop;
     const double lo2 = thr2 / 4096.0;
     int n0;
@@ -549,27 +551,40 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     }
     int c_prev = -1;
     double tau2_prev = -1.0;
+    const int lane = tid & 63, wv = tid >> 6, gc = lane & 15, gk = lane >> 4;
     for (int it = 0; it < 5; it++) {
-        double acc[45];
-#pragma unroll
-        for (int j = 0; j < 45; j++) acc[j] = 0;
+        // Normal matrix N = R^T R of the selected constraint rows r = [x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1]
+        // as a Gram product on the fp64 matrix core: v_mfma_f64_16x16x4_f64 takes A[i][k] and B[k][j] from lane
+        // (i or j = lane & 15, k = lane >> 4); with A = R^T and B = R both operands are the same register, R[k][lane & 15].
+        // Each thread stages the row of its correspondence in LDS (zeros when it is not selected), each wavefront
+        // multiplies its 64 rows in 16 steps; the cross-lane sums happen inside the MFMA.
+        v4d gram = {0.0, 0.0, 0.0, 0.0};
         int cnt = 0;
         double sd = 0;
         {
             double E[9];
             for (int j = 0; j < 9; j++) E[j] = s_E[j];
-            for (int i = tid; i < m; i += TVF_BLOCK) {
-                double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
-                double d = sampson(E, x1, y1, x2, y2);
-                if (d <= tau2) {
-                    double r[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
-                    int k = 0;
+            for (int base = 0; base < m; base += TVF_BLOCK) {  // block-uniform trip count
+                const int i = base + tid;
+                double r[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                if (i < m) {
+                    double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
+                    double d = sampson(E, x1, y1, x2, y2);
+                    if (d <= tau2) {
+                        r[0] = x2 * x1; r[1] = x2 * y1; r[2] = x2; r[3] = y2 * x1; r[4] = y2 * y1; r[5] = y2;
+                        r[6] = x1; r[7] = y1; r[8] = 1.0;
+                        cnt++;
+                        sd += d;
+                    }
+                }
+                __syncthreads();  // the previous pass has been consumed
 #pragma unroll
-                    for (int p = 0; p < 9; p++)
-#pragma unroll
-                        for (int q = p; q < 9; q++) acc[k++] += r[p] * r[q];
-                    cnt++;
-                    sd += d;
+                for (int j = 0; j < 9; j++) s_R[tid * 9 + j] = r[j];
+                __syncthreads();
+#pragma unroll 4
+                for (int s4 = 0; s4 < 16; s4++) {
+                    const double v = gc < 9 ? s_R[(wv * 64 + 4 * s4 + gk) * 9 + gc] : 0.0;
+                    gram = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, gram, 0, 0, 0);
                 }
             }
         }
@@ -578,18 +593,15 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
         if (c == c_prev && tau2 == tau2_prev) break;  // same selection size at the same threshold: converged
         c_prev = c; tau2_prev = tau2;
         const double sds = block_sum(sd, s_red);
-        // 45 sums: wave shuffle reduction, per-wave partials in LDS, one barrier (unrolled: a dynamic index would
-        // push the accumulators into scratch memory)
+        // per-wavefront 16x16 partial Gram tiles (result row = (lane >> 4) + 4 reg, column = lane & 15) -> 45 sums
 #pragma unroll
-        for (int j = 0; j < 45; j++) {
-            double v = acc[j];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if ((tid & 63) == 0) s_part[tid >> 6][j] = v;
-        }
+        for (int rg = 0; rg < 4; rg++) s_tile[wv][(gk + 4 * rg) * 16 + gc] = gram[rg];
         __syncthreads();
         if (tid < 45) {
+            int p = 0, q = tid;
+            while (q >= 9 - p) { q -= 9 - p; p++; }  // packed upper-triangle index -> (p, p + q)
             double v = 0;
-            for (int k = 0; k < TVF_BLOCK / 64; k++) v += s_part[k][tid];
+            for (int k = 0; k < TVF_BLOCK / 64; k++) v += s_tile[k][p * 16 + p + q];
             s_N[tid] = v;
         }
         __syncthreads();
