@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     __shared__ uint32_t s_wq[4][192];  // per-wavefront queue of pixels that pass the compass pre-test
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int t = P.fast_threshold;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: loop control stays on the scalar unit
 
     // ---- 1. stage pixels: rows y0-4 .. y0+rows+3, columns gx0 .. gx0+TW (gx0 = (xs0-3) rounded down to 4)
     const int gx0 = (xs0 - 3) & ~3, lead = xs0 - 3 - gx0;
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
             for (int cc = lane; cc < tw_used; cc += 64) s_tile[r * TW + cc] = (gx0 + cc < lv.w) ? src[cc] : 0;
         }
     }
+    for (int i = tid; i < ((rows + 2) * SW + 3) >> 2; i += 256) ((uint32_t*)s_score)[i] = 0;  // score 0 unless phase 2b says otherwise
     __syncthreads();
 
     // ---- 2. scores.
@@ -381,24 +383,24 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
         int qn = 0;  // wave-uniform queue fill
         int r = 0, j = wv;
         while (j >= nxc) { j -= nxc; r++; }
-        while (r < rows + 2) {
+        while (r < rows + 2) {  // r, j, qn are wave-uniform (scalar registers)
             const int x = (j << 6) + lane;
             bool pass = false;
-            const int pos = r * SW + x;
             if (x < SW) {
-                const uint8_t* p = &s_tile[(r + 3) * TW + x + 3 + lead];
+                const uint8_t* p = &s_tile[(r + 3) * TW + 3 + lead + x];
                 const int v = p[0];
                 const int d0 = v - p[3 * TW], d4 = v - p[3], d8 = v - p[-3 * TW], d12 = v - p[-3];
-                const int nd = (d0 > t) + (d4 > t) + (d8 > t) + (d12 > t);
-                const int nb = (d0 < -t) + (d4 < -t) + (d8 < -t) + (d12 < -t);
-                pass = nd >= 2 || nb >= 2;
-                if (!pass) s_score[pos] = 0;
+                // >= 2 of the 4 differences above t  <=>  their second largest > t; >= 2 below -t <=> second smallest < -t
+                const int mn_a = min(d0, d4), mx_a = max(d0, d4), mn_b = min(d8, d12), mx_b = max(d8, d12);
+                const int second_hi = max(max(min(mx_a, mx_b), mn_a), mn_b);
+                const int second_lo = min(min(max(mn_a, mn_b), mx_a), mx_b);
+                pass = max(second_hi, -second_lo) > t;
             }
             const unsigned long long m = __ballot(pass);
             if (pass) wq[qn + __popcll(m & lt)] = ((uint32_t)r << 16) | (uint32_t)x;
             qn += __popcll(m);
-            replay::wave_sync();
             if (qn >= 128) {
+                replay::wave_sync();  // queue writes of this wavefront are visible to all its lanes
                 score_pair(wq[2 * lane], wq[2 * lane + 1]);
                 qn -= 128;
                 const uint32_t carry = wq[128 + lane];  // <= 63 left-over entries move to the front
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
             j += 4;
             while (j >= nxc) { j -= nxc; r++; }
         }
+        replay::wave_sync();
         if (2 * lane < qn) score_pair(wq[2 * lane], wq[min(2 * lane + 1, qn - 1)]);
     }
     __syncthreads();
