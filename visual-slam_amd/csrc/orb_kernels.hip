@@ -312,23 +312,33 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     uint8_t* s_score = smem;            // (R+2) rows x SW
     uint8_t* s_tile = smem + score_bytes;
     __shared__ int s_wsum[4];
-    __shared__ uint32_t s_wq[4][192];  // per-wavefront queue of pixels that pass the compass pre-test
+    __shared__ uint32_t s_wq[4][256];  // per-wavefront queue of pixels that pass the compass pre-test
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int t = P.fast_threshold;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: loop control stays on the scalar unit
 
-    // ---- 1. stage pixels: rows y0-4 .. y0+rows+3, columns gx0 .. gx0+TW (gx0 = (xs0-3) rounded down to 4)
-    const int gx0 = (xs0 - 3) & ~3, lead = xs0 - 3 - gx0;
-    const int tw_used = (SW + 6 + lead + 3) & ~3, th = rows + 8, gy0 = y0 - 4;
-    if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {
-        const int tw4 = tw_used >> 2;
+    // ---- 1. stage pixels: rows y0-4 .. y0+rows+3, columns gx0 .. gx0+tw_used (gx0 = xs0-3 rounded down to 16, or to 4
+    //         when the level is not 16-byte aligned)
+    const bool al16 = (lv.pitch & 15) == 0 && (((size_t)img) & 15) == 0;
+    const bool al4 = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
+    const int gx0 = al16 ? (xs0 - 3) & ~15 : (xs0 - 3) & ~3, lead = xs0 - 3 - gx0;
+    const int th = rows + 8, gy0 = y0 - 4;
+    if (al16) {  // 16 bytes per lane; pitch >= the rounded row end because pitch is a multiple of 16
+        const int tw16 = (SW + 6 + lead + 15) >> 4;
+        for (int i = tid; i < th * tw16; i += 256) {
+            const int r = i / tw16, c16 = i - r * tw16;
+            *(uint4*)(s_tile + r * TW + 16 * c16) = *(const uint4*)(img + (size_t)(gy0 + r) * lv.pitch + gx0 + 16 * c16);
+        }
+    } else if (al4) {
+        const int tw4 = (SW + 6 + lead + 3) >> 2;
         for (int r = wv; r < th; r += 4) {
             const uint32_t* src = (const uint32_t*)(img + (size_t)(gy0 + r) * lv.pitch + gx0);
             uint32_t* dst = (uint32_t*)(s_tile + r * TW);
             for (int c4 = lane; c4 < tw4; c4 += 64) dst[c4] = src[c4];
         }
     } else {
+        const int tw_used = (SW + 6 + lead + 3) & ~3;
         for (int r = wv; r < th; r += 4) {
             const uint8_t* src = img + (size_t)(gy0 + r) * lv.pitch + gx0;
             for (int cc = lane; cc < tw_used; cc += 64) s_tile[r * TW + cc] = (gx0 + cc < lv.w) ? src[cc] : 0;
@@ -381,35 +391,45 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
         const unsigned long long lt = (1ull << lane) - 1ull;
         const int nxc = (SW + 63) >> 6;
         int qn = 0;  // wave-uniform queue fill
-        int r = 0, j = wv;
-        while (j >= nxc) { j -= nxc; r++; }
-        while (r < rows + 2) {  // r, j, qn are wave-uniform (scalar registers)
-            const int x = (j << 6) + lane;
-            bool pass = false;
-            if (x < SW) {
-                const uint8_t* p = &s_tile[(r + 3) * TW + 3 + lead + x];
-                const int v = p[0];
-                const int d0 = v - p[3 * TW], d4 = v - p[3], d8 = v - p[-3 * TW], d12 = v - p[-3];
-                // >= 2 of the 4 differences above t  <=>  their second largest > t; >= 2 below -t <=> second smallest < -t
-                const int mn_a = min(d0, d4), mx_a = max(d0, d4), mn_b = min(d8, d12), mx_b = max(d8, d12);
-                const int second_hi = max(max(min(mx_a, mx_b), mn_a), mn_b);
-                const int second_lo = min(min(max(mn_a, mn_b), mx_a), mx_b);
-                pass = max(second_hi, -second_lo) > t;
-            }
-            const unsigned long long m = __ballot(pass);
-            if (pass) wq[qn + __popcll(m & lt)] = ((uint32_t)r << 16) | (uint32_t)x;
-            qn += __popcll(m);
-            if (qn >= 128) {
+        // 64-pixel chunks of the scored rows, numbered row-major; each trip takes two of them (chunk c and c + 4) so that
+        // ten independent LDS reads are in flight.  r*, j*, qn are wave-uniform (scalar registers).
+        int ra = 0, ja = wv, rb = 0, jb = wv + 4;
+        while (ja >= nxc) { ja -= nxc; ra++; }
+        while (jb >= nxc) { jb -= nxc; rb++; }
+        auto compass = [&](int r, int x) -> bool {
+            const uint8_t* p = &s_tile[(r + 3) * TW + 3 + lead + x];
+            const int v = p[0];
+            const int d0 = v - p[3 * TW], d4 = v - p[3], d8 = v - p[-3 * TW], d12 = v - p[-3];
+            // >= 2 of the 4 differences above t  <=>  their second largest > t; >= 2 below -t <=> second smallest < -t
+            const int mn_a = min(d0, d4), mx_a = max(d0, d4), mn_b = min(d8, d12), mx_b = max(d8, d12);
+            const int second_hi = max(max(min(mx_a, mx_b), mn_a), mn_b);
+            const int second_lo = min(min(max(mn_a, mn_b), mx_a), mx_b);
+            return max(second_hi, -second_lo) > t;
+        };
+        while (ra < rows + 2) {
+            const int xa = (ja << 6) + lane, xb = (jb << 6) + lane;
+            const bool live_b = rb < rows + 2;
+            const bool pa = xa < SW && compass(ra, xa);
+            const bool pb = live_b && xb < SW && compass(rb, xb);
+            const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+            const int na = __popcll(ma);
+            if (pa) wq[qn + __popcll(ma & lt)] = ((uint32_t)ra << 16) | (uint32_t)xa;
+            if (pb) wq[qn + na + __popcll(mb & lt)] = ((uint32_t)rb << 16) | (uint32_t)xb;
+            qn += na + __popcll(mb);
+            if (qn >= 128) {  // at most 127 + 128 entries are queued
                 replay::wave_sync();  // queue writes of this wavefront are visible to all its lanes
                 score_pair(wq[2 * lane], wq[2 * lane + 1]);
                 qn -= 128;
-                const uint32_t carry = wq[128 + lane];  // <= 63 left-over entries move to the front
+                const uint32_t c0 = wq[128 + lane], c1 = wq[192 + lane];  // <= 127 left-over entries move to the front
                 replay::wave_sync();
-                if (lane < qn) wq[lane] = carry;
+                if (lane < qn) wq[lane] = c0;
+                if (64 + lane < qn) wq[64 + lane] = c1;
                 replay::wave_sync();
             }
-            j += 4;
-            while (j >= nxc) { j -= nxc; r++; }
+            ja += 8;
+            while (ja >= nxc) { ja -= nxc; ra++; }
+            jb += 8;
+            while (jb >= nxc) { jb -= nxc; rb++; }
         }
         replay::wave_sync();
         if (2 * lane < qn) score_pair(wq[2 * lane], wq[min(2 * lane + 1, qn - 1)]);
@@ -493,7 +513,7 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
     for (int L = 0; L < P.nlevels; L++) {
         const LevelInfo& v = P.lv[L];
         score_bytes = std::max(score_bytes, (((size_t)(v.strip_rows + 2) * (v.bw + 2) + 15) & ~(size_t)15));
-        tw_need = std::max(tw_need, (v.bw + 2 + 6 + 3 + 3) & ~3);
+        tw_need = std::max(tw_need, (v.bw + 2 + 6 + 15 + 15) & ~15);
         max_rows = std::max(max_rows, v.strip_rows);
     }
     if (P.strips_per_frame < 1) return MO_OK;
