@@ -781,24 +781,54 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
 
 #define DP_RAW_PITCH 36   // 31 columns + <= 3 alignment lead-in, 9 dwords
 #define DP_BLR_PITCH 44   // 39 columns + <= 3 alignment lead-in, 11 dwords
-#define DP_WAVE_BYTES (31 * DP_RAW_PITCH + 39 * DP_BLR_PITCH)
+#define DP_PATCH_BYTES (39 * DP_BLR_PITCH)  // one LDS patch per keypoint: first the raw 31x31 window, then the blurred 39x39 one
 
 #define DG 16                 // lanes per keypoint (a quarter of a wavefront)
 #define DK_PER_WG (256 / DG)  // keypoints per 256-thread workgroup
 
-// stage a rows x ndw-dword window whose first column is x0a (a multiple of 4) into a group-private LDS patch;
-// gl = lane within the DG-lane group: one row per trip, ndw <= 11 of the 16 lanes active
-__device__ __forceinline__ void stage_patch(const uint8_t* img, int pitch, int x0a, int y0, int rows, int ndw, uint8_t* dst,
-                                            int dpitch, int gl, bool aligned) {
-    if (aligned) {
-        if (gl < ndw)
-            for (int r = 0; r < rows; r++)
-                *(uint32_t*)(dst + r * dpitch + 4 * gl) = *(const uint32_t*)(img + (size_t)(y0 + r) * pitch + x0a + 4 * gl);
-    } else {
-        for (int i = gl; i < rows * ndw * 4; i += DG) {
-            int r = i / (ndw * 4), cidx = i - r * (ndw * 4);
-            dst[r * dpitch + cidx] = (x0a + cidx < pitch) ? img[(size_t)(y0 + r) * pitch + x0a + cidx] : 0;
+// A ROWS x NDW-dword window whose first column is x0a (a multiple of 4), spread over the DG lanes of a keypoint group:
+// lane gl holds dwords gl, gl + 16, gl + 32, ... of the row-major window.  patch_load only issues the global loads (the
+// registers are consumed later, so the loads of both patches are in flight together); patch_store puts them into LDS.
+template <int ROWS, int NDW, int N>
+__device__ __forceinline__ void patch_load(const uint8_t* img, int pitch, int x0a, int y0, int gl, bool aligned, uint32_t (&reg)[N]) {
+    static_assert(N * DG >= ROWS * NDW && (N - 1) * DG < ROWS * NDW && NDW <= DG && 2 * NDW > DG, "register tile shape");
+    int r = 0, c = gl;
+    if (c >= NDW) { c -= NDW; r = 1; }
+    if (aligned) {  // the caller keeps x0a + 4 NDW <= pitch: every dword of the window lies inside its row
+        const uint8_t* base = img + (size_t)y0 * pitch + x0a;
+        int off = r * pitch + 4 * c;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            if (k == N - 1) off = min(r, ROWS - 1) * pitch + 4 * c;  // only the last trip can run past the window: re-read a valid dword
+            reg[k] = *(const uint32_t*)(base + off);
+            c += DG - NDW; r += 1; off += pitch + 4 * (DG - NDW);       // advance 16 dwords: one row down and DG - NDW to the right,
+            if (c >= NDW) { c -= NDW; r += 1; off += pitch - 4 * NDW; }  // wrapping once more when that passes the row end
         }
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < N; k++) {
+            uint32_t v = 0;
+            if (r < ROWS) {
+                const uint8_t* p = img + (size_t)(y0 + r) * pitch + x0a + 4 * c;
+                for (int bq = 0; bq < 4; bq++)
+                    if (x0a + 4 * c + bq < pitch) v |= (uint32_t)p[bq] << (8 * bq);
+            }
+            reg[k] = v;
+            c += DG - NDW; r += 1;
+            if (c >= NDW) { c -= NDW; r += 1; }
+        }
+    }
+}
+
+template <int ROWS, int NDW, int N>
+__device__ __forceinline__ void patch_store(uint8_t* dst, int dpitch, int gl, const uint32_t (&reg)[N]) {
+    int r = 0, c = gl;
+    if (c >= NDW) { c -= NDW; r = 1; }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (k < N - 1 || r < ROWS) *(uint32_t*)(dst + r * dpitch + 4 * c) = reg[k];
+        c += DG - NDW; r += 1;
+        if (c >= NDW) { c -= NDW; r += 1; }
     }
 }
 
@@ -830,15 +860,18 @@ __device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch,
 }
 
 // One 16-lane group (a quarter wavefront) per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred
-// patch (rBRIEF) are staged in LDS with aligned dword loads; orientation sums and the 256 rotated tests then read LDS only.
-// Four keypoints share one wavefront's instruction stream for the per-keypoint scalar work (level lookup, fastAtan2, the
-// f64 sincos): the kernel is instruction-bound, so this is what sets its speed.
+// patch (rBRIEF) pass through the same group-private LDS patch one after the other: all global loads of both windows are
+// issued up front into registers, the raw window is stored and reduced to the angle while the blurred one is still in
+// flight, then the blurred window takes its place.  A patch is only touched by the 16 lanes of its group, which sit in
+// one wavefront and execute in lockstep, so no barrier is needed.  1716 B of LDS per keypoint (27 KB per workgroup,
+// 5 workgroups per CU) is what sets the speed: the kernel is bound by load latency x occupancy.
+template <bool HAS_DESC>  // compile-time: a run-time branch around the blurred loads would hide their count from s_waitcnt
 __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                                   const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
                                                   int* flags) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_WAVE_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_PATCH_BYTES];
     const int frame = blockIdx.y;
     const int grp = threadIdx.x / DG, gl = threadIdx.x % DG;
     const int k = blockIdx.x * DK_PER_WG + grp;
@@ -853,73 +886,76 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         counts[frame] = total;
         if (total > cap) atomicOr(&flags[0], 2);
     }
-    const bool active = L >= 0 && k < cap;  // uniform within the group
-    uint8_t* s_raw = s_patch + grp * DP_WAVE_BYTES;
-    uint8_t* s_blr = s_raw + 31 * DP_RAW_PITCH;
-    const LevelInfo lv = P.lv[active ? L : 0];
-    int x = 0, y = 0, offr = 0, offb = 0;
-    float response = 0.f, px = 0.f, py = 0.f;
-    if (active) {
-        FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
-        x = fk.x; y = fk.y; response = fk.response;
-        px = (float)x * lv.scale; py = (float)y * lv.scale;
-        const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
-        const int xr0 = (x - 15) & ~3;
-        offr = (x - 15) - xr0;
-        const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
-        stage_patch(img, lv.pitch, xr0, y - 15, 31, min(9, (lv.pitch - xr0) >> 2), s_raw, DP_RAW_PITCH, gl, al_raw);
-        if (desc) {
-            float inv = 1.f / lv.scale;
-            int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
-            const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
-            const int xb0 = (cx - 19) & ~3;
-            offb = (cx - 19) - xb0;
-            stage_patch(bl, lv.bpitch, xb0, cy - 19, 39, min(11, (lv.bpitch - xb0) >> 2), s_blr, DP_BLR_PITCH, gl, true);
-        }
+    if (L < 0 || k >= cap) return;  // uniform within the group; no barriers below
+    uint8_t* s_p = s_patch + grp * DP_PATCH_BYTES;
+    const LevelInfo lv = P.lv[L];
+    const FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
+    const int x = fk.x, y = fk.y;
+    const float px = (float)x * lv.scale, py = (float)y * lv.scale;
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    // aligned 9-dword (11-dword) window start, moved left when it would cross the end of the row
+    const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0 && lv.pitch >= 36;
+    const int xr0 = al_raw ? min((x - 15) & ~3, lv.pitch - 36) : (x - 15) & ~3, offr = (x - 15) - xr0;
+    // half-widths of the two disc rows of this lane: fetched before the patch loads, whose s_waitcnt they would otherwise share
+    const int dsc0 = P.umax[15 - gl], dsc1 = P.umax[min(gl + 1, 15)];
+    uint32_t raw[18], blr[27];
+    patch_load<31, 9>(img, lv.pitch, xr0, y - 15, gl, al_raw, raw);
+    int offb = 0;
+    if (HAS_DESC) {
+        const float inv = 1.f / lv.scale;
+        const int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
+        const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
+        const int xb0 = min((cx - 19) & ~3, lv.bpitch - 44);
+        offb = (cx - 19) - xb0;
+        patch_load<39, 11>(bl, lv.bpitch, xb0, cy - 19, gl, true, blr);
     }
-    __syncthreads();
+    patch_store<31, 9>(s_p, DP_RAW_PITCH, gl, raw);
     // intensity centroid over the radius-15 disc: rows gl and gl + 16 of the 31 on each lane
     int m10 = 0, m01 = 0;
-    if (active) {
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int row_i = gl + rr * DG;
-            if (row_i < 31) {
-                int v = row_i - 15;
-                int d = P.umax[v < 0 ? -v : v];
-                const uint8_t* row = s_raw + row_i * DP_RAW_PITCH + 15 + offr;
-                int rs = 0;
-                for (int u = -d; u <= d; u++) {
-                    int p = row[u];
-                    m10 += u * p;
-                    rs += p;
-                }
-                m01 += v * rs;
+    for (int rr = 0; rr < 2; rr++) {
+        const int row_i = gl + rr * DG;
+        if (row_i < 31) {
+            const int v = row_i - 15;
+            const int d = rr == 0 ? dsc0 : dsc1;
+            const uint8_t* row = s_p + row_i * DP_RAW_PITCH + 15 + offr;
+            int rs = 0;
+            for (int u = -d; u <= d; u++) {
+                int p = row[u];
+                m10 += u * p;
+                rs += p;
             }
+            m01 += v * rs;
         }
     }
     m10 = group_sum(m10);
     m01 = group_sum(m01);
-    if (!active) return;
-    float angle = fast_atan2_deg((float)m01, (float)m10);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
     mo_keypoint* o = kps + (size_t)frame * cap + k;
     if (gl == 0) {
         o->x = px; o->y = py;
         o->size = 31 * lv.scale;
         o->angle = angle;
-        o->response = response;
+        o->response = fk.response;
         o->octave = L;
         o->class_id = -1;
     }
-    if (desc)  // patch-local centre (19 + offb, 19); bounds guaranteed by edge_threshold >= 19 and pattern radius <= 18
-        *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) = rbrief_u16(s_blr, DP_BLR_PITCH, 19 + offb, 19, angle, gl);
+    if (HAS_DESC) {  // patch-local centre (19 + offb, 19); bounds guaranteed by edge_threshold >= 19 and pattern radius <= 18
+        patch_store<39, 11>(s_p, DP_BLR_PITCH, gl, blr);
+        *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) = rbrief_u16(s_p, DP_BLR_PITCH, 19 + offb, 19, angle, gl);
+    }
 }
 
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
                         int* d_counts) {
     const Plan& P = c->plan;
-    hipLaunchKernelGGL(k_describe, dim3((cap + DK_PER_WG - 1) / DK_PER_WG, batch), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur,
-                       c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->d_flags);
+    const dim3 grid((cap + DK_PER_WG - 1) / DK_PER_WG, batch);
+    if (d_desc)
+        hipLaunchKernelGGL(k_describe<true>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
+                           d_kps, d_desc, cap, d_counts, c->d_flags);
+    else
+        hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
+                           d_kps, d_desc, cap, d_counts, c->d_flags);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
