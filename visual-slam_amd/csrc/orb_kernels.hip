@@ -66,6 +66,13 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * RS_TW, ty0 = blockIdx.y * RS_TH;
     const uint8_t* s = src + (size_t)blockIdx.z * src_fstride;
+    // source window of the tile from four wave-uniform (scalar) table reads, so that the coefficient tables and the
+    // source pixels are fetched in the same round trip and one barrier covers both
+    const int sx0 = xofs[tx0], sx1 = min(xofs[min(tx0 + RS_TW - 1, dw - 1)] + 1, sw - 1);
+    const int sy0 = yofs[ty0], sy1 = min(yofs[min(ty0 + RS_TH - 1, dh - 1)] + 1, sh - 1);
+    const int sxa = sx0 & ~3;
+    const int ncols = sx1 - sxa + 1, nrows = sy1 - sy0 + 1;
+    if (ncols > RS_SRC_PITCH || nrows > RS_SRC_ROWS) return;  // scale factor > 2: not supported by this tile shape (host checks)
     if (tid < RS_TW) {
         int x = min(tx0 + tid, dw - 1);
         s_xo[tid] = xofs[x];
@@ -75,12 +82,6 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         s_yo[tid - RS_TW] = yofs[y];
         s_yc[tid - RS_TW] = yc1[y];
     }
-    __syncthreads();
-    const int sx0 = s_xo[0], sx1 = min(s_xo[RS_TW - 1] + 1, sw - 1);
-    const int sy0 = s_yo[0], sy1 = min(s_yo[RS_TH - 1] + 1, sh - 1);
-    const int sxa = sx0 & ~3;
-    const int ncols = sx1 - sxa + 1, nrows = sy1 - sy0 + 1;
-    if (ncols > RS_SRC_PITCH || nrows > RS_SRC_ROWS) return;  // scale factor > 2: not supported by this tile shape (host checks)
     if ((spitch & 3) == 0 && (((size_t)s) & 3) == 0) {
         const int ndw = (ncols + 3) >> 2;
         for (int i = tid; i < nrows * ndw; i += 256) {
