@@ -50,11 +50,11 @@ int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, ui
 
 // ------------------------------------------------------------------ resize --------------------------
 #define RS_TW 64
-#define RS_TH 16
-#define RS_SRC_ROWS 40    // source rows a 16-row output tile can touch (scale <= 2) + 1
+#define RS_TH 32
+#define RS_SRC_ROWS 72    // source rows a 32-row output tile can touch (scale <= 2) + 1
 #define RS_SRC_PITCH 144  // source columns a 64-column output tile can touch (scale <= 2) + alignment lead-in
 
-// INTER_LINEAR_EXACT level L from level L-1: one workgroup = 64x16 output tile.  The source window is staged in LDS
+// INTER_LINEAR_EXACT level L from level L-1: one workgroup = 64x32 output tile.  The source window is staged in LDS
 // with aligned dword loads, the per-column / per-row fixed-point coefficients (built on the host in cv2's double
 // arithmetic) are cached in LDS, each thread produces 4 adjacent pixels and stores one dword.
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
@@ -95,25 +95,36 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         }
     }
     __syncthreads();
-    const int ry = tid >> 4, c0 = (tid & 15) * 4;
-    const int x = tx0 + c0, y = ty0 + ry;
-    if (y >= dh || x >= dw) return;
-    const int oy = s_yo[ry] - sy0, oy1 = min(s_yo[ry] + 1, sh - 1) - sy0;
-    const uint32_t my1 = s_yc[ry], my0 = 256 - my1;
-    const uint8_t* r0 = s_src + oy * RS_SRC_PITCH;
-    const uint8_t* r1 = s_src + oy1 * RS_SRC_PITCH;
-    uint32_t packed = 0;
+    const int c0 = (tid & 15) * 4, x = tx0 + c0;
+    if (x >= dw) return;
+    int ox[4], ox1[4];
+    uint32_t mx1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int ox = s_xo[c0 + k] - sxa, ox1 = min(s_xo[c0 + k] + 1, sw - 1) - sxa;
-        const uint32_t mx1 = s_xc[c0 + k], mx0 = 256 - mx1;
-        uint32_t h0 = mx0 * r0[ox] + mx1 * r0[ox1];
-        uint32_t h1 = mx0 * r1[ox] + mx1 * r1[ox1];
-        uint32_t v = my0 * h0 + my1 * h1;
-        packed |= ((v + 32768u) >> 16) << (8 * k);
+        ox[k] = s_xo[c0 + k] - sxa;
+        ox1[k] = min(s_xo[c0 + k] + 1, sw - 1) - sxa;
+        mx1[k] = s_xc[c0 + k];
     }
-    // dpitch is a multiple of 16 >= dw: the <= 3 bytes past dw land in row padding
-    *(uint32_t*)(dst + (size_t)blockIdx.z * dst_fstride + (size_t)y * dpitch + x) = packed;
+#pragma unroll
+    for (int half = 0; half < RS_TH / 16; half++) {  // each thread: 4 adjacent pixels of rows ry and ry + 16
+        const int ry = (tid >> 4) + 16 * half, y = ty0 + ry;
+        if (y >= dh) break;
+        const int oy = s_yo[ry] - sy0, oy1 = min(s_yo[ry] + 1, sh - 1) - sy0;
+        const uint32_t my1 = s_yc[ry], my0 = 256 - my1;
+        const uint8_t* r0 = s_src + oy * RS_SRC_PITCH;
+        const uint8_t* r1 = s_src + oy1 * RS_SRC_PITCH;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t mx0 = 256 - mx1[k];
+            uint32_t h0 = mx0 * r0[ox[k]] + mx1[k] * r0[ox1[k]];
+            uint32_t h1 = mx0 * r1[ox[k]] + mx1[k] * r1[ox1[k]];
+            uint32_t v = my0 * h0 + my1 * h1;
+            packed |= ((v + 32768u) >> 16) << (8 * k);
+        }
+        // dpitch is a multiple of 16 >= dw: the <= 3 bytes past dw land in row padding
+        *(uint32_t*)(dst + (size_t)blockIdx.z * dst_fstride + (size_t)y * dpitch + x) = packed;
+    }
 }
 
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
