@@ -536,8 +536,8 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_BUF_BYTES (48 * 1024)  // LDS record window: u32 FAST records, then u64 Harris records overlaid
-#define SEL_MAXSTRIPS 1024
+#define SEL_BUF_BYTES (38 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): 4 workgroups per CU
+#define SEL_MAXSTRIPS 256
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
 __device__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
