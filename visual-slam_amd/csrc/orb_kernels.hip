@@ -620,7 +620,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less)
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
     __shared__ int s_n[2];
-    const int L = level0 + blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;  // dispatch order: all frames of the finest level first
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
     if (lv.nstrips == 0) {
@@ -689,18 +689,12 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BUF_BYTES));
         c->lds_attr_done |= 16u;
     }
-    // Two launches: the fine levels (most candidates) get the full LDS record window, the coarse levels (less than a third
-    // of level 0's pixels) a quarter of it, so four times as many of their workgroups are resident.  The replays are
-    // latency-bound single wavefronts: residency is what buys throughput.  A level that outgrows its window falls back to
-    // its HBM scratch slot (same code, slower).
-    int split = 1;
-    while (split < P.nlevels && (long long)P.lv[split].w * P.lv[split].h * 3 > (long long)P.lv[0].w * P.lv[0].h) split++;
-    hipLaunchKernelGGL(k_select, dim3(split, batch), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+    // One launch, every workgroup with the full LDS record window (4 resident per CU), levels in dispatch order from fine to
+    // coarse: the replays are latency-bound single wavefronts whose length grows with the candidate count, so the long
+    // level-0 tasks start first and the short coarse-level tasks fill the slots that free up (longest-task-first packing).
+    // A level that outgrows the window falls back to its HBM scratch slot (same code, slower).
+    hipLaunchKernelGGL(k_select, dim3(batch, P.nlevels), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
                        c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags, 0, SEL_BUF_BYTES);
-    if (split < P.nlevels)
-        hipLaunchKernelGGL(k_select, dim3(P.nlevels - split, batch), dim3(SEL_THREADS), SEL_BUF_BYTES / 4, c->stream, P, d_gray,
-                           c->d_pyr, c->d_cand, c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt,
-                           c->d_flags, split, SEL_BUF_BYTES / 4);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
