@@ -64,7 +64,7 @@ def test_fast_nms_candidates(ctx, O, thr):
 def _retain_cases():
     rng = np.random.default_rng(5)
     cases = []
-    for n in (1, 2, 3, 4, 7, 31, 32, 33, 34, 40, 41, 42, 64, 100, 257, 1000, 5000, 20000):
+    for n in (1, 2, 3, 4, 7, 31, 32, 33, 34, 40, 41, 42, 64, 100, 257, 383, 385, 640, 1000, 1025, 3711, 5000, 16385, 16800, 20000):
         for kind in ("float", "ties", "sorted", "rsorted", "const"):
             if kind == "float": r = rng.normal(size=n).astype(np.float32)
             elif kind == "ties": r = rng.integers(0, 12, size=n).astype(np.float32)

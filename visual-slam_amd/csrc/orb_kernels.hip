@@ -536,7 +536,7 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_BUF_BYTES (38 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): 4 workgroups per CU
+#define SEL_BUF_BYTES (37 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): 4 workgroups per CU
 #define SEL_MAXSTRIPS 256
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
@@ -575,12 +575,12 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
 
 #define SEL_THREADS 256
 
-// phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order, all 4 wavefronts), retainBest(quota)
-// replayed by wavefront 0, write-out by all
+// phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota) replay, write-out;
+// all by the whole workgroup
 template <class PA, class PB>
 __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1,
                                               uint16_t* rpos, unsigned long long* bl, FinalKp* fin, int* fin_cnt_out,
-                                              int* flags, int* s_n) {
+                                              int* flags, replay::WgScratch* ws) {
     const int tid = threadIdx.x;
     for (int i = tid; i < N1; i += SEL_THREADS) {
         uint32_t e = A[i];
@@ -589,12 +589,7 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
         B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
     }
     __syncthreads();
-    if (tid < WAVE) {
-        int n2 = replay::wave_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid);
-        if (tid == 0) s_n[1] = n2;
-    }
-    __syncthreads();
-    int N2 = s_n[1];
+    int N2 = replay::wg_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid, ws);
     if (N2 > lv.fin_cap) {
         if (tid == 0) atomicOr(&flags[0], 1);
         N2 = lv.fin_cap;
@@ -610,8 +605,8 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
     if (tid == 0) *fin_cnt_out = N2;
 }
 
-// One workgroup (4 wavefronts) per (frame, level).  Gather, Harris and write-out use all wavefronts; the two
-// retainBest replays run on wavefront 0 (wave-parallel pairing partition, select_replay.h).
+// One workgroup (4 wavefronts) per (frame, level).  Gather, Harris, write-out and the partition passes of the two
+// retainBest replays use all wavefronts (workgroup-parallel pairing partition, select_replay.h).
 __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                         const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
                                                         uint64_t* __restrict__ scratch, size_t scratch_stride,
@@ -619,7 +614,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
                                                         int level0, int buf_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less)
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
-    __shared__ int s_n[2];
+    __shared__ replay::WgScratch s_ws;
     const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;  // dispatch order: all frames of the finest level first
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
@@ -658,15 +653,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
         }
     }
     __syncthreads();
-    // pass 1: retainBest(2 * quota) on the FAST score (wavefront 0)
-    if (tid < WAVE) {
-        int n1;
-        if (a_lds) n1 = replay::wave_retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, tid);
-        else n1 = replay::wave_retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, tid);
-        if (tid == 0) s_n[0] = n1;
-    }
-    __syncthreads();
-    const int N1 = s_n[0];
+    // pass 1: retainBest(2 * quota) on the FAST score
+    const int N1 = a_lds ? replay::wg_retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, tid, &s_ws)
+                         : replay::wg_retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, tid, &s_ws);
     // the Harris records (and their rpos / ballots) go behind the surviving FAST records when both fit the window
     const size_t b_off = a_lds ? (((size_t)N1 * 4 + 15) & ~(size_t)15) : 0;
     const bool b_lds = b_off + sel_need_bytes(N1, 8) <= (size_t)buf_bytes;
@@ -675,10 +664,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     unsigned long long* b_bl = (unsigned long long*)((uint8_t*)b_rpos + ((((size_t)N1 / 2 + 1) * 2 + 7) & ~(size_t)7));
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
-    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, s_n);
-    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, s_n);
-    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, s_n);
-    else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, s_n);
+    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws);
+    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws);
+    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws);
+    else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws);
 }
 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
@@ -700,13 +689,14 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
 }
 
 // probe for the parity tests: retainBest on a bare float response array (u64 record path, HBM-resident records)
-__global__ __launch_bounds__(64) void k_retain_probe(const float* resp, int n, int n_points, int order, uint64_t* rec,
-                                                     uint16_t* rpos, unsigned long long* bl, int32_t* out, int* nout) {
-    for (int i = threadIdx.x; i < n; i += 64) rec[i] = ((uint64_t)__float_as_uint(resp[i]) << 32) | (uint32_t)i;
+__global__ __launch_bounds__(SEL_THREADS) void k_retain_probe(const float* resp, int n, int n_points, int order, uint64_t* rec,
+                                                              uint16_t* rpos, unsigned long long* bl, int32_t* out, int* nout) {
+    __shared__ replay::WgScratch s_ws;
+    for (int i = threadIdx.x; i < n; i += SEL_THREADS) rec[i] = ((uint64_t)__float_as_uint(resp[i]) << 32) | (uint32_t)i;
     __syncthreads();
-    int keep = replay::wave_retain_best<uint64_t>(rec, n, n_points, order, rpos, bl, threadIdx.x);
+    int keep = replay::wg_retain_best<uint64_t>(rec, n, n_points, order, rpos, bl, threadIdx.x, &s_ws);
     __syncthreads();
-    for (int i = threadIdx.x; i < keep; i += 64) out[i] = (int32_t)(rec[i] & 0xFFFFFFFFu);
+    for (int i = threadIdx.x; i < keep; i += SEL_THREADS) out[i] = (int32_t)(rec[i] & 0xFFFFFFFFu);
     if (threadIdx.x == 0) *nout = keep;
 }
 
@@ -716,7 +706,7 @@ int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points,
     int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, rec_b + rpos_b + bl_b);
     if (rc) return rc;
     uint8_t* b = (uint8_t*)c->d_tmp;
-    hipLaunchKernelGGL(k_retain_probe, dim3(1), dim3(64), 0, c->stream, d_resp, n, n_points, order, (uint64_t*)b,
+    hipLaunchKernelGGL(k_retain_probe, dim3(1), dim3(SEL_THREADS), 0, c->stream, d_resp, n, n_points, order, (uint64_t*)b,
                        (uint16_t*)(b + rec_b), (unsigned long long*)(b + rec_b + rpos_b), d_order, d_nout);
     HIPCHK(c, hipGetLastError());
     return MO_OK;

@@ -470,4 +470,217 @@ __device__ __forceinline__ int wave_retain_best(P a, int n, int n_points, int or
     return n_points + total_true;
 }
 
+// ================================================================ workgroup-parallel replay (4 wavefronts) ==========
+// The same pairing partition with the 256-element trips dealt round-robin to the 4 wavefronts of a 256-thread workgroup.
+// Trip t (elements lo + 256 t ..) needs the number of left / right stoppers in the trips before it: pass 1 leaves the
+// per-trip counts in LDS, one wavefront turns them into exclusive prefix sums (<= 64 trips: one shuffle scan), passes 2
+// and 3 then run independently per trip.  K and the cut are combined over the wavefronts (positions grow with the trip
+// number, so the minimum over the wavefronts' first hits is the global first hit).  All 256 threads call these functions
+// convergently; every branch below depends only on values that are identical in all threads.
+struct WgScratch {
+    int cl[64], cr[64], pl[65], pr[65];
+    int k[4], nl[4], sr[4];
+    int cut;
+};
+#define WG_THREADS 256
+#define WG_PARTITION_MIN 384     // shorter ranges: one wavefront does it alone (saves the barriers)
+#define WG_PARTITION_MAX 16384   // 64 trips: what one shuffle scan covers
+
+template <class T, class P, class FL, class FR>
+__device__ __forceinline__ int wg_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
+                                                 int tid, WgScratch* ws, int* total_r) {
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int ntrip = (hi - lo + 64 * RP_EPL - 1) / (64 * RP_EPL);
+    // pass 1: ballots of the left stoppers (kept for pass 3) and per-trip stopper counts
+    for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
+        const int c0 = lo + t * 64 * RP_EPL;
+        T v[RP_EPL];
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            int i = c0 + RP_EPL * lane + k;
+            v[k] = a[i < hi ? i : lo];
+        }
+        int tl = 0, tr = 0;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            bool in = c0 + RP_EPL * lane + k < hi;
+            unsigned long long mL = __ballot(in && stopL(v[k])), mR = __ballot(in && stopR(v[k]));
+            if (lane == 0) bl[t * RP_EPL + k] = mL;
+            tl += __popcll(mL);
+            tr += __popcll(mR);
+        }
+        if (lane == 0) { ws->cl[t] = tl; ws->cr[t] = tr; }
+    }
+    __syncthreads();
+    if (wv == 0) {  // exclusive prefix sums over the trips
+        int l = lane < ntrip ? ws->cl[lane] : 0, r = lane < ntrip ? ws->cr[lane] : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int nl = __shfl_up(l, o, 64), nr = __shfl_up(r, o, 64);
+            if (lane >= o) { l += nl; r += nr; }
+        }
+        ws->pl[lane + 1] = l;
+        ws->pr[lane + 1] = r;
+        if (lane == 0) { ws->pl[0] = 0; ws->pr[0] = 0; }
+    }
+    __syncthreads();
+    const int TR = ws->pr[ntrip];
+    // pass 2: which stoppers swap, where their partners are, K and the cut
+    int Kw = 0, minNL = 0x7FFFFFFF, minSR = 0x7FFFFFFF;
+    bool foundNL = false, foundSR = false;
+    for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
+        const int c0 = lo + t * 64 * RP_EPL;
+        const int baseL = ws->pl[t], baseR = ws->pr[t];
+        T v[RP_EPL];
+        int nl_pos = 0x7FFFFFFF, sr_pos = 0x7FFFFFFF;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            int i = c0 + RP_EPL * lane + k;
+            v[k] = a[i < hi ? i : lo];
+        }
+        bool isL[RP_EPL], isR[RP_EPL];
+        int pl = 0, pr = 0;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            bool in = c0 + RP_EPL * lane + k < hi;
+            isL[k] = in && stopL(v[k]);
+            isR[k] = in && stopR(v[k]);
+            unsigned long long mL = __ballot(isL[k]), mR = __ballot(isR[k]);
+            pl += __popcll(mL & lt); pr += __popcll(mR & lt);
+        }
+        int cL = baseL + pl, cR = baseR + pr;   // stoppers strictly before this lane's first element
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            const int i = c0 + RP_EPL * lane + k;
+            const int kL = cL + 1, kR = TR - cR;
+            const bool swL = isL[k] && (TR - cR - (isR[k] ? 1 : 0)) >= kL;   // R_kL lies strictly right of this element
+            const bool swR = isR[k] && cL >= kR;                              // L_kR lies strictly left of this element
+            if (swR) rpos[kR - 1] = (uint16_t)(i - lo);
+            if (isL[k] && !swL) nl_pos = min(nl_pos, i);
+            if (swR) sr_pos = min(sr_pos, i);
+            Kw += __popcll(__ballot(swL));
+            cL += isL[k] ? 1 : 0;
+            cR += isR[k] ? 1 : 0;
+        }
+        if (!foundNL) {
+            unsigned long long mk = __ballot(nl_pos != 0x7FFFFFFF);
+            if (mk) { minNL = __builtin_amdgcn_readlane(nl_pos, __ffsll((long long)mk) - 1); foundNL = true; }
+        }
+        if (!foundSR) {
+            unsigned long long mk = __ballot(sr_pos != 0x7FFFFFFF);
+            if (mk) { minSR = __builtin_amdgcn_readlane(sr_pos, __ffsll((long long)mk) - 1); foundSR = true; }
+        }
+    }
+    if (lane == 0) { ws->k[wv] = Kw; ws->nl[wv] = minNL; ws->sr[wv] = minSR; }
+    __syncthreads();
+    const int K = ws->k[0] + ws->k[1] + ws->k[2] + ws->k[3];
+    const int cut = min(min(min(ws->nl[0], ws->nl[1]), min(ws->nl[2], ws->nl[3])),
+                        min(min(ws->sr[0], ws->sr[1]), min(ws->sr[2], ws->sr[3])));
+    // pass 3: the swaps (a left stopper of rank <= K with the right stopper of the same rank)
+    for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
+        const int baseL = ws->pl[t];
+        if (baseL >= K) break;
+        const int c0 = lo + t * 64 * RP_EPL;
+        unsigned long long mL[RP_EPL];
+        int pl = 0;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            mL[k] = bl[t * RP_EPL + k];
+            pl += __popcll(mL[k] & lt);
+        }
+        int cL = baseL + pl;
+#pragma unroll
+        for (int k = 0; k < RP_EPL; k++) {
+            if ((mL[k] >> lane) & 1ull) {
+                const int kL = cL + 1;
+                if (kL <= K) {
+                    int p = c0 + RP_EPL * lane + k, q = lo + rpos[kL - 1];
+                    T vp = a[p], vq = a[q];
+                    a[p] = vq;
+                    a[q] = vp;
+                }
+                cL++;
+            }
+        }
+    }
+    __syncthreads();
+    if (total_r) *total_r = TR;
+    return cut;
+}
+
+// one partition step for the whole workgroup: cooperative when the range is long enough, else wavefront 0 alone
+template <class T, class P, class FL, class FR>
+__device__ __forceinline__ int wg_partition_step(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
+                                                 int tid, WgScratch* ws, int* total_r) {
+    const int n = hi - lo;
+    if (n >= WG_PARTITION_MIN && n <= WG_PARTITION_MAX) return wg_pair_partition<T>(a, lo, hi, stopL, stopR, rpos, bl, tid, ws, total_r);
+    if (tid < 64) {
+        int tr = 0;
+        int c = wave_pair_partition<T>(a, lo, hi, stopL, stopR, rpos, bl, tid, &tr);
+        if (tid == 0) { ws->cut = c; ws->k[0] = tr; }
+    }
+    __syncthreads();
+    const int c = ws->cut;
+    if (total_r) *total_r = ws->k[0];
+    __syncthreads();  // ws is reused by the next step
+    return c;
+}
+
+template <class T, class P>
+__device__ __forceinline__ void wg_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int tid,
+                                                  WgScratch* ws) {
+    typedef Rec<T> R;
+    if (first == last || nth == last) return;
+    int depth = (31 - __clz(last - first)) * 2;
+    while (last - first > 3) {
+        if (last - first < REPLAY_SERIAL_BELOW || last - first > 65535 || depth == 0) {
+            if (tid == 0) ls_introselect<T>(a, first, nth, last, depth);  // identical continuation, one lane
+            __syncthreads();
+            return;
+        }
+        --depth;
+        int mid = first + (last - first) / 2;
+        if (tid == 0) ls_move_median_to_first<T>(a, first, first + 1, mid, last - 1);
+        __syncthreads();
+        const T pv = a[first];
+        int cut = wg_partition_step<T>(
+            a, first + 1, last, [pv](T v) { return !R::gt(v, pv); }, [pv](T v) { return !R::gt(pv, v); }, rpos, bl, tid, ws,
+            (int*)nullptr);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    if (tid == 0) ls_insertion_sort<T>(a, first, last);
+    __syncthreads();
+}
+
+// retainBest for a 256-thread workgroup, all threads convergent; every thread returns the same count
+template <class T, class P>
+__device__ __forceinline__ int wg_retain_best(P a, int n, int n_points, int order, uint16_t* rpos, unsigned long long* bl, int tid,
+                                              WgScratch* ws) {
+    typedef Rec<T> R;
+    if (n_points < 0 || n <= n_points) return n;
+    if (n_points == 0) return 0;
+    if (order == MO_ORDER_MSVC) {
+        if (tid == 0) ms_nth_element<T>(a, 0, n_points - 1, n);
+        __syncthreads();
+    } else {
+        wg_ls_nth_element<T>(a, 0, n_points - 1, n, rpos, bl, tid, ws);
+    }
+    const T amb = a[n_points - 1];
+    const int tail = n - n_points;
+    if (tail < REPLAY_SERIAL_BELOW || tail > 65535) {
+        if (tid == 0) ws->cut = partition_ge<T>(a, n_points, n, amb);
+        __syncthreads();
+        const int keep = ws->cut;
+        __syncthreads();
+        return n_points + keep;
+    }
+    int total_true = 0;
+    wg_partition_step<T>(
+        a, n_points, n, [amb](T v) { return !R::ge(v, amb); }, [amb](T v) { return R::ge(v, amb); }, rpos, bl, tid, ws,
+        &total_true);
+    return n_points + total_true;
+}
+
 }  // namespace replay
