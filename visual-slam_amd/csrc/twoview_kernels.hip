@@ -28,13 +28,16 @@ struct TvWork {
     int* qidx;         // [pairs][cap] query keypoint index of correspondence i
     int* m;            // [pairs]
     double* hypE;      // [pairs][n_hyp][9]
-    unsigned long long* best;  // [pairs] (count << 32) | (0xFFFFFFFF - hyp)
+    unsigned long long* best;  // [pairs] (float32 bits of the MSAC cost << 32) | hypothesis index, minimum wins
+    double* part;      // [pairs][n_hyp] MSAC cost over the first tv_first(m) correspondences (staged scoring)
+    unsigned* bound;   // [pairs] float32 bits of an upper bound of the best total cost (staged scoring)
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
     size_t p = (size_t)n_pairs;
     return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 +
-           p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + 1024;
+           p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + p * (size_t)n_hyp * sizeof(double) +
+           p * sizeof(unsigned) + 1024;
 }
 
 static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
@@ -44,9 +47,11 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     w.xn = (double*)b; b += p * cap * 4 * sizeof(double);
     w.hypE = (double*)b; b += p * (size_t)n_hyp * 9 * sizeof(double);
     w.best = (unsigned long long*)b; b += p * sizeof(unsigned long long);
+    w.part = (double*)b; b += p * (size_t)n_hyp * sizeof(double);
     w.px = (float*)b; b += p * cap * 4 * sizeof(float);
     w.qidx = (int*)b; b += p * cap * sizeof(int);
-    w.m = (int*)b;
+    w.m = (int*)b; b += p * sizeof(int);
+    w.bound = (unsigned*)b;
     return w;
 }
 
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     double* xn = w.xn + (size_t)pair * a.cap * 4;
     float* px = w.px + (size_t)pair * a.cap * 4;
     int* qidx = w.qidx + (size_t)pair * a.cap;
-    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; }
+    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; w.bound[pair] = 0x7F800000u; }
     __syncthreads();
     if (a.d_p1) {  // explicit correspondences
         int m = a.m_fixed;
@@ -386,7 +391,10 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
 
 // ---------------------------------------------------------------- hypotheses ----------------------
 
-__global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
+// correspondences summed by the first scoring stage: a quarter of them, at least 32
+__device__ __forceinline__ int tv_first(int m) { return min(m, max(32, (m + 3) >> 2)); }
+
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, int staged) {
     __shared__ unsigned long long s_best[TV_BLOCK / 64];
     const int pair = blockIdx.y, tid = threadIdx.x;
     const int h = blockIdx.x * TV_BLOCK + tid;
@@ -414,28 +422,116 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w) {
     // models that catch more chance inliers).  Compared as float32, ties -> lowest hypothesis index.
     // The correspondences are the same for every lane: they arrive through wave-uniform scalar loads (constant address
     // space; k_tv_prep wrote them in an earlier launch) and feed the fp64 FMAs as scalar operands, one per instruction.
+    //
+    // Staged scoring (exact): this kernel only sums the first F = tv_first(m) correspondences and stores that partial
+    // cost.  The hypothesis with the smallest partial cost of each block is then scored completely by the whole block;
+    // its total (rounded up) is an upper bound of the best total of the pair.  A hypothesis whose PARTIAL cost already
+    // exceeds the bound cannot win (costs only grow), so k_tv_score finishes only the others -- typically 5-20 % --
+    // packed densely into wavefronts.
+    typedef const __attribute__((address_space(4))) double* cdp;
+    const cdp pts = (cdp)(uintptr_t)xn;
+    const int F = staged ? tv_first(m) : m;
     double cost = 0.0;
     if (valid) {
-        typedef const __attribute__((address_space(4))) double* cdp;
-        const cdp pts = (cdp)(uintptr_t)xn;
 #pragma unroll 4
-        for (int i = 0; i < m; i++) {
+        for (int i = 0; i < F; i++) {
             double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
             cost += fmin(err, thr2);
         }
     }
     unsigned long long key = ~0ull;
     if (valid && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
+    if (staged && h < a.n_hyp) w.part[(size_t)pair * a.n_hyp + h] = key != ~0ull ? cost : __longlong_as_double(0x7FF0000000000000ll);
+    const unsigned long long own = key;
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long other = __shfl_xor(key, o, 64);
         key = other < key ? other : key;
     }
     if ((tid & 63) == 0) s_best[tid >> 6] = key;
     __syncthreads();
-    if (tid == 0) {
-        for (int k = 1; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;
-        if (key != ~0ull) atomicMin(&w.best[pair], key);
+    for (int k = 0; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;  // block minimum, in every thread
+    if (!staged) {
+        if (tid == 0 && key != ~0ull) atomicMin(&w.best[pair], key);
+        return;
     }
+    if (key == ~0ull) return;  // no valid hypothesis in this block (block-uniform)
+    // the block's candidate: total cost by all threads -> bound
+    __shared__ double s_cand[10];
+    __shared__ double s_sum[TV_BLOCK / 64];
+    if (own == key) {
+        for (int j = 0; j < 9; j++) s_cand[j] = E[j];
+        s_cand[9] = cost;
+    }
+    __syncthreads();
+    double Ec[9];
+    for (int j = 0; j < 9; j++) Ec[j] = s_cand[j];
+    double rest = 0.0;
+    for (int i = F + tid; i < m; i += TV_BLOCK)
+        rest += fmin(sampson_fast(Ec, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]), thr2);
+    for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o, 64);
+    if ((tid & 63) == 0) s_sum[tid >> 6] = rest;
+    __syncthreads();
+    if (tid == 0) {
+        double total = s_cand[9];
+        for (int k = 0; k < TV_BLOCK / 64; k++) total += s_sum[k];
+        // this sum is associated differently from the canonical (sequential) one: two float32 ulps upwards cover that
+        // and the rounding to float32, so the bound never undercuts the candidate's canonical cost
+        atomicMin(&w.bound[pair], __float_as_uint((float)total) + 2u);
+    }
+}
+
+// Second stage of the staged scoring: one wavefront per 64 surviving hypotheses.  Every wavefront of a pair rebuilds the
+// same compact list of survivors (float32(partial cost) <= bound) from the stored partial costs, takes its share of it,
+// and continues each survivor's sequential sum over the remaining correspondences: bit-identical to an unstaged sum.
+#define TVS_WAVES 16  // wavefronts per pair
+__global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
+    extern __shared__ unsigned short s_list[];  // [n_hyp]
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int m = w.m[pair];
+    if (m < 8) return;
+    const unsigned bound = w.bound[pair];
+    const double* part = w.part + (size_t)pair * a.n_hyp;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int total = 0;
+    for (int h0 = 0; h0 < a.n_hyp; h0 += 64) {
+        const int h = h0 + lane;
+        const bool alive = h < a.n_hyp && __float_as_uint((float)part[h]) <= bound;  // costs are >= 0: bit order = value order
+        const unsigned long long mk = __ballot(alive);
+        if (alive) s_list[total + __popcll(mk & lt)] = (unsigned short)h;
+        total += __popcll(mk);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+    const double thr2 = thr * thr;
+    const double* xn = w.xn + (size_t)pair * a.cap * 4;
+    typedef const __attribute__((address_space(4))) double* cdp;
+    const cdp pts = (cdp)(uintptr_t)xn;
+    const int F = tv_first(m);
+    unsigned long long key = ~0ull;
+    for (int t0 = blockIdx.x * 64; t0 < total; t0 += gridDim.x * 64) {
+        const bool on = t0 + lane < total;
+        const int h = s_list[on ? t0 + lane : t0];
+        const double* Eg = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
+        double E[9];
+        for (int j = 0; j < 9; j++) E[j] = Eg[j];
+        double cost = part[h];
+#pragma unroll 4
+        for (int i = F; i < m; i++) {
+            double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
+            cost += fmin(err, thr2);
+        }
+        if (on && cost == cost) {
+            unsigned long long k2 = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
+            key = k2 < key ? k2 : key;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        unsigned long long other = __shfl_xor(key, o, 64);
+        key = other < key ? other : key;
+    }
+    if (lane == 0 && key != ~0ull) atomicMin(&w.best[pair], key);
 }
 
 // ---------------------------------------------------------------- finish --------------------------
@@ -756,7 +852,10 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
     if (rc) return rc;
     TvWork w = carve(c->d_tv, a.n_pairs, a.cap, a.n_hyp);
     hipLaunchKernelGGL(k_tv_prep, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
-    hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+    const int staged = a.n_hyp >= 512 && a.n_hyp <= 16384;  // the survivor list of k_tv_score is u16 in LDS
+    hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged);
+    if (staged)
+        hipLaunchKernelGGL(k_tv_score, dim3(TVS_WAVES, a.n_pairs), dim3(64), (size_t)a.n_hyp * sizeof(unsigned short), c->stream, a, w);
     hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
