@@ -10,7 +10,10 @@
 //   k_tv_prep    per pair: gather the ratio-test survivors (query order) -> normalised f64 correspondences
 //   k_tv_hyp     one thread per hypothesis: counter-based 8-sample, 8x9 null vector by Householder QR (registers),
 //                projection on the essential manifold (3x3 SVD via Jacobi), MSAC cost (truncated Sampson distance)
-//                over all correspondences, which arrive as scalar operands; block min -> one atomicMin per block
+//                over the FIRST QUARTER of the correspondences, which arrive as scalar operands; the block's most
+//                promising hypothesis is scored completely -> upper bound of the pair's best cost
+//   k_tv_compact / k_tv_score   hypotheses whose partial cost already exceeds the bound cannot win; the others (about a
+//                fifth) are listed and finished, 64 per wavefront -> exact argmin, one atomicMin per wavefront
 //   k_tv_finish  one block per pair: consensus set of the best hypothesis -> adaptive-threshold least-squares
 //                8-point refits (9x9 normal matrix, inverse iteration) -> final inliers -> decompose E -> cheirality
 //                vote over the 4 (R, t) candidates with per-point DLT -> final DLT triangulation in pixel space
@@ -31,13 +34,15 @@ struct TvWork {
     unsigned long long* best;  // [pairs] (float32 bits of the MSAC cost << 32) | hypothesis index, minimum wins
     double* part;      // [pairs][n_hyp] MSAC cost over the first tv_first(m) correspondences (staged scoring)
     unsigned* bound;   // [pairs] float32 bits of an upper bound of the best total cost (staged scoring)
+    unsigned short* list;  // [pairs][n_hyp] hypotheses that survive the bound (any order)
+    int* n_alive;      // [pairs]
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
     size_t p = (size_t)n_pairs;
     return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 +
            p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + p * (size_t)n_hyp * sizeof(double) +
-           p * sizeof(unsigned) + 1024;
+           p * sizeof(unsigned) + p * (size_t)n_hyp * sizeof(unsigned short) + p * sizeof(int) + 1024;
 }
 
 static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
@@ -51,7 +56,9 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     w.px = (float*)b; b += p * cap * 4 * sizeof(float);
     w.qidx = (int*)b; b += p * cap * sizeof(int);
     w.m = (int*)b; b += p * sizeof(int);
-    w.bound = (unsigned*)b;
+    w.bound = (unsigned*)b; b += p * sizeof(unsigned);
+    w.n_alive = (int*)b; b += p * sizeof(int);
+    w.list = (unsigned short*)b;
     return w;
 }
 
@@ -480,53 +487,59 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     }
 }
 
-// Second stage of the staged scoring: one wavefront per 64 surviving hypotheses.  Every wavefront of a pair rebuilds the
-// same compact list of survivors (float32(partial cost) <= bound) from the stored partial costs, takes its share of it,
-// and continues each survivor's sequential sum over the remaining correspondences: bit-identical to an unstaged sum.
-#define TVS_WAVES 16  // wavefronts per pair
-__global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
-    extern __shared__ unsigned short s_list[];  // [n_hyp]
-    const int pair = blockIdx.y, lane = threadIdx.x;
+// Second stage of the staged scoring.  k_tv_compact lists the survivors of a pair (float32(partial cost) <= bound; the
+// order is irrelevant for a minimum); k_tv_score gives every 64 of them one wavefront, which continues each survivor's
+// sequential sum over the remaining correspondences: bit-identical to an unstaged sum.
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_compact(TwoViewArgs a, TvWork w) {
+    __shared__ int s_cnt;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
     const int m = w.m[pair];
-    if (m < 8) return;
-    const unsigned bound = w.bound[pair];
-    const double* part = w.part + (size_t)pair * a.n_hyp;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    int total = 0;
-    for (int h0 = 0; h0 < a.n_hyp; h0 += 64) {
-        const int h = h0 + lane;
-        const bool alive = h < a.n_hyp && __float_as_uint((float)part[h]) <= bound;  // costs are >= 0: bit order = value order
-        const unsigned long long mk = __ballot(alive);
-        if (alive) s_list[total + __popcll(mk & lt)] = (unsigned short)h;
-        total += __popcll(mk);
+    if (m >= 8) {
+        const unsigned bound = w.bound[pair];
+        const double* part = w.part + (size_t)pair * a.n_hyp;
+        unsigned short* list = w.list + (size_t)pair * a.n_hyp;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int h0 = 0; h0 < a.n_hyp; h0 += TV_BLOCK) {  // block-uniform trip count
+            const int h = h0 + tid;
+            const bool alive = h < a.n_hyp && __float_as_uint((float)part[h]) <= bound;  // costs are >= 0: bit order = value order
+            const unsigned long long mk = __ballot(alive);
+            int base = 0;
+            if (lane == 0 && mk) base = atomicAdd(&s_cnt, __popcll(mk));
+            base = __shfl(base, 0, 64);
+            if (alive) list[base + __popcll(mk & lt)] = (unsigned short)h;
+        }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __syncthreads();
+    if (tid == 0) w.n_alive[pair] = s_cnt;
+}
+
+__global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int total = w.n_alive[pair];
+    const int t0 = blockIdx.x * 64;
+    if (t0 >= total) return;
+    const int m = w.m[pair];
     const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
     const double thr2 = thr * thr;
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
     typedef const __attribute__((address_space(4))) double* cdp;
     const cdp pts = (cdp)(uintptr_t)xn;
     const int F = tv_first(m);
-    unsigned long long key = ~0ull;
-    for (int t0 = blockIdx.x * 64; t0 < total; t0 += gridDim.x * 64) {
-        const bool on = t0 + lane < total;
-        const int h = s_list[on ? t0 + lane : t0];
-        const double* Eg = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
-        double E[9];
-        for (int j = 0; j < 9; j++) E[j] = Eg[j];
-        double cost = part[h];
+    const bool on = t0 + lane < total;
+    const int h = w.list[(size_t)pair * a.n_hyp + (on ? t0 + lane : t0)];
+    const double* Eg = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
+    double E[9];
+    for (int j = 0; j < 9; j++) E[j] = Eg[j];
+    double cost = w.part[(size_t)pair * a.n_hyp + h];
 #pragma unroll 4
-        for (int i = F; i < m; i++) {
-            double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
-            cost += fmin(err, thr2);
-        }
-        if (on && cost == cost) {
-            unsigned long long k2 = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
-            key = k2 < key ? k2 : key;
-        }
+    for (int i = F; i < m; i++) {
+        double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
+        cost += fmin(err, thr2);
     }
+    unsigned long long key = ~0ull;
+    if (on && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long other = __shfl_xor(key, o, 64);
         key = other < key ? other : key;
@@ -852,10 +865,12 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
     if (rc) return rc;
     TvWork w = carve(c->d_tv, a.n_pairs, a.cap, a.n_hyp);
     hipLaunchKernelGGL(k_tv_prep, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
-    const int staged = a.n_hyp >= 512 && a.n_hyp <= 16384;  // the survivor list of k_tv_score is u16 in LDS
+    const int staged = a.n_hyp >= 512 && a.n_hyp <= 65536;  // the survivor list is u16
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged);
-    if (staged)
-        hipLaunchKernelGGL(k_tv_score, dim3(TVS_WAVES, a.n_pairs), dim3(64), (size_t)a.n_hyp * sizeof(unsigned short), c->stream, a, w);
+    if (staged) {
+        hipLaunchKernelGGL(k_tv_compact, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+        hipLaunchKernelGGL(k_tv_score, dim3((a.n_hyp + 63) / 64, a.n_pairs), dim3(64), 0, c->stream, a, w);
+    }
     hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
