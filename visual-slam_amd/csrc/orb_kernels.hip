@@ -177,14 +177,22 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* 
     const int tx0 = (tile % T.tx[L]) * BT_W, ty0 = (tile / T.tx[L]) * BT_H;
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int tid = threadIdx.x;
-    // s_px column c holds level column tx0 - 4 + c  (c = 1 .. 70 are used)
-    const bool interior = tx0 >= 4 && ty0 >= 3 && tx0 + BT_W + 4 <= lv.w && ty0 + BT_H + 3 <= lv.h &&
-                          (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0;
-    if (interior) {
+    // s_px column c holds level column tx0 - 4 + c  (c = 1 .. 70 are used).  Rows are reflected per tile row
+    // (REFLECT_101); a dword whose four columns lie inside the level is one aligned load, the few that touch the left or
+    // right border are assembled from reflected bytes -- border tiles cost about the same as interior ones.
+    if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {
         for (int i = tid; i < BT_ROWS * 18; i += 256) {
-            int r = i / 18, c4 = i - r * 18;
-            const uint32_t* src = (const uint32_t*)(img + (size_t)(ty0 + r - 3) * lv.pitch + tx0 - 4);
-            ((uint32_t*)(s_px + r * BT_PW))[c4] = src[c4];
+            const int r = i / 18, c4 = i - r * 18;
+            const int y = reflect101(ty0 + r - 3, lv.h), x0 = tx0 - 4 + 4 * c4;
+            const uint8_t* row = img + (size_t)y * lv.pitch;
+            uint32_t v;
+            if (x0 >= 0 && x0 + 3 < lv.w) v = *(const uint32_t*)(row + x0);
+            else {
+                v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(x0 + b, lv.w)] << (8 * b);
+            }
+            ((uint32_t*)(s_px + r * BT_PW))[c4] = v;
         }
     } else {
         for (int i = tid; i < BT_ROWS * (BT_W + 6); i += 256) {
