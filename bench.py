@@ -276,6 +276,16 @@ def main():
                                  "integer-VALU / latency bound, far from the HBM roof (see DESIGN.md)"},
             "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
         }
+        # the one matrix-core kernel of the path: int8 operations of the +-127 distance product (2 * 256 per descriptor pair)
+        # against the dense int8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md)
+        if per_stage.get("match_knn2_ratio", 0) > 0:
+            c64 = cnt.astype(np.float64)
+            ops = 0.0
+            for sb_cnt in np.split(c64, np.cumsum([sb.io.batch for sb in subs])[:-1]):
+                ops += float((sb_cnt[:-1] * sb_cnt[1:]).sum()) * 512.0
+            tops = ops / (per_stage["match_knn2_ratio"] * 1e-3) / 1e12
+            out["roofline_matcher"] = {"bound": "mfma", "kernel": "k_match_mfma", "achieved": round(tops, 1), "peak": 5000.0,
+                                       "unit": "TOP/s", "frac": round(tops / 5000.0, 4), "dtype": "int8"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames].cpu().numpy(), args.cpu_frames, K)
         print(json.dumps(out), flush=True)
