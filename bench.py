@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches (HIP streams) per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optin", action="store_true", help="skip the extra timing of the opt-in matrix-core matcher")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the batch the CPU baseline is timed on (~10 s)")
     args = ap.parse_args()
 
@@ -276,16 +277,36 @@ def main():
                                  "integer-VALU / latency bound, far from the HBM roof (see DESIGN.md)"},
             "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
         }
-        # the one matrix-core kernel of the path: int8 operations of the +-127 distance product (2 * 256 per descriptor pair)
-        # against the dense int8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md)
-        if per_stage.get("match_knn2_ratio", 0) > 0:
-            c64 = cnt.astype(np.float64)
-            ops = 0.0
-            for sb_cnt in np.split(c64, np.cumsum([sb.io.batch for sb in subs])[:-1]):
-                ops += float((sb_cnt[:-1] * sb_cnt[1:]).sum()) * 512.0
-            tops = ops / (per_stage["match_knn2_ratio"] * 1e-3) / 1e12
-            out["roofline_matcher"] = {"bound": "mfma", "kernel": "k_match_mfma", "achieved": round(tops, 1), "peak": 5000.0,
-                                       "unit": "TOP/s", "frac": round(tops / 5000.0, 4), "dtype": "int8"}
+        # Opt-in variant, timed outside the headline region on the same inputs: the matrix-core matcher
+        # (VSLAM_AMD_MATCHER=mfma at context creation; identical results).  Its int8 operations (2 * 256 per descriptor
+        # pair) are priced against the dense int8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md).
+        if world == 1 and S == 1 and not args.no_optin:
+            os.environ["VSLAM_AMD_MATCHER"] = "mfma"
+            try:
+                sb2 = SubBatch(0, n_pairs)
+            finally:
+                os.environ.pop("VSLAM_AMD_MATCHER", None)
+            for _ in range(max(1, args.warmup)):
+                sb2.launch()
+            torch.cuda.synchronize()
+            acc2 = {}
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sb2.launch()
+                for name, ms in sb2.ctx.stage_times():
+                    acc2[name] = acc2.get(name, 0.0) + ms
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            m_ms = acc2.get("match_knn2_ratio", 0.0) / args.steps
+            c64 = sb2.counts.cpu().numpy().astype(np.float64)
+            ops = float((c64[:-1] * c64[1:]).sum()) * 512.0
+            tops = ops / (m_ms * 1e-3) / 1e12 if m_ms > 0 else 0.0
+            out["matcher_mfma_optin"] = {"value": round(B * args.steps / el2, 2), "unit": "frames/s",
+                                         "ms_per_step": round(el2 / args.steps * 1e3, 3), "match_ms": round(m_ms, 4),
+                                         "roofline": {"bound": "mfma", "kernel": "k_match_mfma", "achieved": round(tops, 1),
+                                                      "peak": 5000.0, "unit": "TOP/s", "frac": round(tops / 5000.0, 4),
+                                                      "dtype": "int8"}}
+            sb2.ctx.close()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames].cpu().numpy(), args.cpu_frames, K)
         print(json.dumps(out), flush=True)

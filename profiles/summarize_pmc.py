@@ -10,7 +10,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 STAGES = {"pyramid": ["k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
-          "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_match_mfma"], "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_compact", "k_tv_score", "k_tv_finish"]}
+          "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_match"], "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_compact", "k_tv_score", "k_tv_finish"]}
 STEPS = 4  # 1 warm-up + 3 timed
 
 

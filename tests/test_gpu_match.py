@@ -5,10 +5,20 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=["valu", "mfma"])
+def ctx(request):
+    """Both matcher kernels: the default XOR + popcount one and the opt-in matrix-core one (chosen at context creation)."""
+    import os
     import vslam_amd as V
-    c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=4)
+    old = os.environ.get("VSLAM_AMD_MATCHER")
+    os.environ["VSLAM_AMD_MATCHER"] = request.param
+    try:
+        c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=4)
+    finally:
+        if old is None:
+            os.environ.pop("VSLAM_AMD_MATCHER", None)
+        else:
+            os.environ["VSLAM_AMD_MATCHER"] = old
     yield c
     c.close()
 

@@ -57,7 +57,7 @@ struct mo_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    bool match_valu = false;   // VSLAM_AMD_MATCH_VALU=1: force the vector-ALU matcher (the path for > 32258 train descriptors)
+    bool match_mfma = false;   // VSLAM_AMD_MATCHER=mfma: opt-in matrix-core matcher (default: XOR + popcount on the vector ALU)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_aux0 = nullptr, ev_aux1 = nullptr;

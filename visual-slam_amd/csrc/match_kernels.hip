@@ -2,7 +2,7 @@
 // Replaces cv2.BFMatcher(NORM_HAMMING).knnMatch(d1, d2, k=2) and the Python ratio loop of the reference
 // (src/orbslam2/matcher.py:70,73-81).
 //
-// Integer bit work, no MFMA: each lane owns one query descriptor in 8 VGPRs; the train descriptors are
+// Default path (north_star: integer bit work, no MFMA): each lane owns one query descriptor in 8 VGPRs; the train descriptors are
 // walked by every wave in the same order, so their 32 bytes arrive through wave-uniform (scalar) loads and
 // the inner loop is 8 x (v_xor_b32 + v_bcnt_u32_b32) + a packed (distance << 20 | trainIdx) key folded
 // into the running best / second-best with v_med3_u32 + v_min_u32.  Smallest key == smallest distance,
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Matrix-core path.  The 2000 x 2000 x 256-bit distance table of a pair is a GEMM over +-1 vectors: with every
+// Opt-in matrix-core path (environment VSLAM_AMD_MATCHER=mfma when the context is created; same results bit for bit).
+// The 2000 x 2000 x 256-bit distance table of a pair is a GEMM over +-1 vectors: with every
 // descriptor bit expanded to the int8 value +127 (set) or -127 (clear), a.b = 16129 * (256 - 2 * hamming).  The
 // accumulator of v_mfma_i32_32x32x32_i8 is started at C = 31 - (train row within the tile), so each of its 16 registers
 // ends as  M - (32258 * hamming + row)  with M = 16129 * 256 + 31: ONE signed integer ordered exactly like
@@ -241,7 +242,7 @@ int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t
     if (nq_max <= 0) return MO_OK;
     if ((d_counts ? out_stride : nt_fixed) >= (1 << 20)) return mo_fail(c, MO_ERR_UNSUPPORTED, "more than 2^20-1 train descriptors");
     const int nt_max = d_counts ? out_stride : nt_fixed;
-    if (nt_max <= MM_MAX_TRAIN && !c->match_valu) {
+    if (c->match_mfma && nt_max <= MM_MAX_TRAIN) {
         dim3 grid((nq_max + MM_QPB - 1) / MM_QPB, n_pairs);
         hipLaunchKernelGGL(k_match_mfma, grid, dim3(MM_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf,
                            d_tf, nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
