@@ -47,6 +47,18 @@ def test_config4_two_view(ctx, seed, n, of, gt_tol):
     assert np.isnan(g["X"][~g["pose_mask"]]).all()
 
 
+# the hypothesis scoring is staged (partial cost -> bound -> survivors) for 512 <= n_hyp <= 65536 and plain otherwise; both
+# must pick the oracle's hypothesis.  m = 20 makes the first stage cover every correspondence (nothing left for stage two).
+@pytest.mark.parametrize("n,n_hyp", [(600, 300), (600, 512), (600, 70000), (20, 1024), (40, 4096)])
+def test_staged_and_plain_scoring_agree_with_oracle(ctx, n, n_hyp):
+    s = G.synthetic_two_view(seed=21 + n, n=n, outlier_frac=0.2)
+    g = ctx.init_two_view(s["p1"], s["p2"], s["K"], thr_px=3.0, n_hyp=n_hyp, seed=77)
+    o = G.init_two_view(s["p1"], s["p2"], s["K"], thr_px=3.0, n_hyp=n_hyp, seed=77)
+    assert rel(g["R"], o["R"]) < TOL and rel(g["t"], o["t"]) < TOL
+    assert (g["ransac_mask"] != o["ransac_mask"]).sum() <= 2
+    assert abs(g["n_good"] - o["n_good"]) <= 2
+
+
 def test_triangulate_points_matches_svd(ctx):
     s = G.synthetic_two_view(seed=3, n=300, outlier_frac=0)
     K = s["K"]
