@@ -37,6 +37,17 @@ __device__ __forceinline__ void emit_match_key(uint32_t k0, uint32_t k1, double 
     emit_match(i0, d0, i1, d1, ratio, o, oidx, odist, opass);
 }
 
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {  // popcount(x) + acc in one instruction, kept as a chain
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c) {  // the compiler only forms it for constant clamps
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict__ qbase, const uint8_t* __restrict__ tbase,
                                                       size_t q_stride, size_t t_stride, const int32_t* __restrict__ counts,
                                                       const int32_t* __restrict__ qf, const int32_t* __restrict__ tf,
@@ -58,8 +69,7 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
         for (int k = 0; k < 8; k++) a[m][k] = q[(size_t)qi * 8 + k];
         k0[m] = KEY_NONE; k1[m] = KEY_NONE;
     }
-#pragma unroll 4
-    for (int j = 0; j < nt; j++) {  // 4 train descriptors (scalar loads) in flight per trip
+    auto fold = [&](int j) {
         const uint32_t* b = t + (size_t)j * 8;  // wave-uniform address -> scalar loads
         uint32_t d[MQ_Q];
 #pragma unroll
@@ -68,16 +78,21 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
         for (int k = 0; k < 8; k++) {
             const uint32_t bk = b[k];
 #pragma unroll
-            for (int m = 0; m < MQ_Q; m++) d[m] += __popc(a[m][k] ^ bk);
+            for (int m = 0; m < MQ_Q; m++) d[m] = bcnt_acc(a[m][k] ^ bk, d[m]);
         }
 #pragma unroll
         for (int m = 0; m < MQ_Q; m++) {
             const uint32_t key = (d[m] << 20) | (uint32_t)j;
-            // new second-best = min(k1, max(k0, key)) given k0 <= k1; new best = min(k0, key)
-            k1[m] = min(k1[m], max(k0[m], key));
+            // k0 <= k1: the new second-best is the median of (k0, k1, key), the new best their minimum
+            k1[m] = med3_u32(k0[m], k1[m], key);
             k0[m] = min(k0[m], key);
         }
+    };
+    int j = 0;
+    for (; j + 4 <= nt; j += 4) {  // 4 train descriptors (scalar loads) in flight per trip
+        fold(j); fold(j + 1); fold(j + 2); fold(j + 3);
     }
+    for (; j < nt; j++) fold(j);
 #pragma unroll
     for (int m = 0; m < MQ_Q; m++) {
         const int qi = blockIdx.x * MQ_PER_BLOCK + m * MQ_THREADS + threadIdx.x;
