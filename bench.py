@@ -93,8 +93,49 @@ def metric_name():
         return "frames/sec (extract+match+pose) at 640x480, 2000 ORB, 1/2/4/8 MI355X"
 
 
+def cv2_baseline(frames_u8, n_frames, K):
+    """if cv2 happens to be importable on the GPU box, time cv2 itself with the reference's parameters
+    (extractor.py:38-48, matcher.py:29,70-81, utils.py:120-134) -- the calls the reference makes, not its files."""
+    import cv2
+    cv2.setNumThreads(1)
+    orb = cv2.ORB_create(nfeatures=NFEAT, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, WTA_K=2,
+                         scoreType=cv2.ORB_HARRIS_SCORE, patchSize=31, fastThreshold=7)
+    bf = cv2.BFMatcher(cv2.NORM_HAMMING)
+    t0 = time.perf_counter()
+    feats = [orb.detectAndCompute(frames_u8[i], None) for i in range(n_frames)]
+    t1 = time.perf_counter()
+    good = []
+    for i in range(n_frames - 1):
+        knn = bf.knnMatch(feats[i][1], feats[i + 1][1], k=2)
+        good.append([m[0] for m in knn if len(m) == 1 or m[0].distance < 0.75 * m[1].distance])
+    t2 = time.perf_counter()
+    n_pose = min(12, n_frames - 1)
+    for i in range(n_pose):
+        p1 = np.float32([feats[i][0][m.queryIdx].pt for m in good[i]])
+        p2 = np.float32([feats[i + 1][0][m.trainIdx].pt for m in good[i]])
+        E, mask = cv2.findEssentialMat(p1, p2, K, method=cv2.RANSAC, prob=0.999, threshold=3.0)
+        if E is not None and E.shape == (3, 3):
+            cv2.recoverPose(E, p1, p2, K, mask=mask)
+    t3 = time.perf_counter()
+    per_frame = (t1 - t0) / n_frames + (t2 - t1) / max(n_frames - 1, 1) + (t3 - t2) / max(n_pose, 1)
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": 1, "kind": "reference",
+            "sample": "%d frames cv2.ORB (%.3f s), %d pairs BFMatcher knn + ratio (%.3f s), %d pairs findEssentialMat + "
+                      "recoverPose (%.3f s); cv2 %s, 1 thread" % (n_frames, t1 - t0, n_frames - 1, t2 - t1, n_pose, t3 - t2,
+                                                                  cv2.__version__)}
+
+
 def cpu_baseline(frames_u8, n_frames, K):
-    """The CPU oracle (own C++/numpy restatement; cv2 is not installed) on a bounded sample, 1 core."""
+    """cv2 itself when the box has it (kind "reference"); otherwise the CPU oracle (own C++/numpy restatement, kind
+    "port") on a bounded sample, 1 core."""
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        cv2 = None
+    if cv2 is not None:
+        try:
+            return cv2_baseline(frames_u8, n_frames, K)
+        except Exception as e:  # an unexpected cv2 build: fall back to the port and say so
+            print("cv2 baseline failed (%s); timing the CPU restatement instead" % e, file=sys.stderr)
     from oracle import geom_oracle as G
     from oracle import orb_oracle as O
     O.lib().orc_set_variant(0, 0)
