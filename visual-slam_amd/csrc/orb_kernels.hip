@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* 
     __shared__ __attribute__((aligned(16))) uint8_t s_px[BT_ROWS * BT_PW];
     __shared__ __attribute__((aligned(16))) uint32_t s_row[(BT_ROWS / 2) * BT_W];  // [row pair][column] = lo: even row, hi: odd
     int tile = blockIdx.x, frame = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {  // XCD affinity (speed only): all tiles of a frame on one XCD, so halo re-reads hit its L2
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
+        frame = (lin & 7) + 8 * (n / (int)gridDim.x);
+        tile = n % (int)gridDim.x;
+    }
     int L = 0;
     while (L + 1 < T.nlevels && tile >= T.cum[L + 1]) L++;
     tile -= T.cum[L];
@@ -876,9 +881,17 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
                                                   uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
                                                   int* flags) {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_PATCH_BYTES];
-    const int frame = blockIdx.y;
+    // XCD affinity (speed only, any mapping is correct): consecutive workgroup ids go round-robin to the 8 XCDs, each with
+    // its own L2.  Re-indexing so that all workgroups of a frame share one id residue keeps the frame's two pyramids
+    // (2 MB) in ONE L2 while its keypoints are described, instead of being fetched into eight.
+    int frame = blockIdx.y, wg = blockIdx.x;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
+        frame = (lin & 7) + 8 * (n / (int)gridDim.x);
+        wg = n % (int)gridDim.x;
+    }
     const int grp = threadIdx.x / DG, gl = threadIdx.x % DG;
-    const int k = blockIdx.x * DK_PER_WG + grp;
+    const int k = wg * DK_PER_WG + grp;
     const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
     int total = 0, L = -1, idx = 0;
     for (int l = 0; l < P.nlevels; l++) {
