@@ -64,8 +64,16 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_SRC_ROWS * RS_SRC_PITCH];
     __shared__ int s_xo[RS_TW], s_xc[RS_TW], s_yo[RS_TH], s_yc[RS_TH];
     const int tid = threadIdx.x;
-    const int tx0 = blockIdx.x * RS_TW, ty0 = blockIdx.y * RS_TH;
-    const uint8_t* s = src + (size_t)blockIdx.z * src_fstride;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {  // XCD affinity (speed only): all tiles of a frame on one XCD (the level just written is in its L2)
+        const int per = gridDim.x * gridDim.y, lin = bx + gridDim.x * (by + gridDim.y * bz), n = lin >> 3;
+        bz = (lin & 7) + 8 * (n / per);
+        const int rem = n % per;
+        by = rem / (int)gridDim.x;
+        bx = rem - by * (int)gridDim.x;
+    }
+    const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
+    const uint8_t* s = src + (size_t)bz * src_fstride;
     // source window of the tile from four wave-uniform (scalar) table reads, so that the coefficient tables and the
     // source pixels are fetched in the same round trip and one barrier covers both
     const int sx0 = xofs[tx0], sx1 = min(xofs[min(tx0 + RS_TW - 1, dw - 1)] + 1, sw - 1);
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
             packed |= ((v + 32768u) >> 16) << (8 * k);
         }
         // dpitch is a multiple of 16 >= dw: the <= 3 bytes past dw land in row padding
-        *(uint32_t*)(dst + (size_t)blockIdx.z * dst_fstride + (size_t)y * dpitch + x) = packed;
+        *(uint32_t*)(dst + (size_t)bz * dst_fstride + (size_t)y * dpitch + x) = packed;
     }
 }
 
@@ -324,6 +332,11 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int strip = blockIdx.x, frame = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {  // XCD affinity (speed only): all strips of a frame on one XCD, so halo rows hit its L2
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
+        frame = (lin & 7) + 8 * (n / (int)gridDim.x);
+        strip = n % (int)gridDim.x;
+    }
     int L = 0;
     while (L + 1 < P.nlevels && strip >= P.lv[L + 1].strip_base) L++;
     const LevelInfo lv = P.lv[L];
