@@ -196,6 +196,7 @@ def main():
     from vslam_amd.sharding import gather_map_points, shard
     B = args.batch
     first, nb, n_pairs, _ = shard(rank, world, B)   # rank > 0 re-extracts the frame preceding its shard (halo)
+    pairs_all = [shard(r, world, B)[2] for r in range(world)]
     frames = make_frames(torch, dev, first, nb)
     K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])  # configs/monocular.yaml:3
 
@@ -249,7 +250,7 @@ def main():
         for sb in subs:
             main.wait_stream(sb.stream)
         if world > 1:  # final map-point gather (the only collective on the path)
-            gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0)
+            gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all)
         if collect:
             for sb in subs:
                 for name, ms in sb.ctx.stage_times():

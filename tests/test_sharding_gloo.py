@@ -28,10 +28,13 @@ def _worker(rank, world, port, q):
     first, n, n_pairs, first_pair = shard(rank, world, B)
     pts = fake_points(first_pair, n_pairs, B)
     got = gather_map_points(pts, n_pairs, dst=0)
+    # the caller-supplied pair counts (what bench.py passes) must give the same lists without the count exchange
+    got2 = gather_map_points(pts, n_pairs, dst=0, pairs_per_rank=[shard(r, world, B)[2] for r in range(world)])
     if rank == 0:
+        assert all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(got, got2)) and len(got) == len(got2)
         q.put(torch.cat(got).numpy())
     else:
-        assert got is None
+        assert got is None and got2 is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -18,19 +18,24 @@ def shard(rank, world, frames_per_rank):
     return first, n, n - 1, first
 
 
-def gather_map_points(points, n_pairs, dst=0, group=None):
+def gather_map_points(points, n_pairs, dst=0, group=None, pairs_per_rank=None):
     """points: [rows >= n_pairs, cap, 3] float tensor, NaN where a query keypoint produced no map point.
     Padded gather to `dst` (fixed-size collective: payload is MBs, latency-bound on xGMI).  On dst returns a list
-    with one [n_pairs_r, cap, 3] tensor per rank in global pair order, elsewhere None."""
+    with one [n_pairs_r, cap, 3] tensor per rank in global pair order, elsewhere None.
+    pairs_per_rank: the pair count of every rank when the caller knows it (contiguous sharding does: shard(r, ...)[2]);
+    without it the counts are exchanged with one extra all_gather and a host read per rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return [points[:n_pairs]]
     rank = dist.get_rank(group)
-    meta = torch.tensor([n_pairs], dtype=torch.int64, device=points.device)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
+    if pairs_per_rank is None:
+        meta = torch.tensor([n_pairs], dtype=torch.int64, device=points.device)
+        metas = [torch.zeros_like(meta) for _ in range(world)]
+        dist.all_gather(metas, meta, group=group)
     bufs = [torch.empty_like(points) for _ in range(world)] if rank == dst else None
     dist.gather(points, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return [bufs[r][:int(metas[r].item())] for r in range(world)]
+    if pairs_per_rank is None:
+        pairs_per_rank = [int(m.item()) for m in metas]
+    return [bufs[r][:pairs_per_rank[r]] for r in range(world)]
