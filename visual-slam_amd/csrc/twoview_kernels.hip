@@ -36,13 +36,16 @@ struct TvWork {
     unsigned* bound;   // [pairs] float32 bits of an upper bound of the best total cost (staged scoring)
     unsigned short* list;  // [pairs][n_hyp] hypotheses that survive the bound (any order)
     int* n_alive;      // [pairs]
+    int* n_tasks;      // [1] number of 64-survivor tasks of the whole launch
+    int2* task;        // [pairs * ceil(n_hyp / 64)] (pair, first survivor) of each task, dense from index 0
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
     size_t p = (size_t)n_pairs;
     return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 +
            p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + p * (size_t)n_hyp * sizeof(double) +
-           p * sizeof(unsigned) + p * (size_t)n_hyp * sizeof(unsigned short) + p * sizeof(int) + 1024;
+           p * sizeof(unsigned) + p * (size_t)n_hyp * sizeof(unsigned short) + p * sizeof(int) + 16 +
+           p * (size_t)((n_hyp + 63) / 64) * sizeof(int2) + 1024;
 }
 
 static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
@@ -58,6 +61,8 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     w.m = (int*)b; b += p * sizeof(int);
     w.bound = (unsigned*)b; b += p * sizeof(unsigned);
     w.n_alive = (int*)b; b += p * sizeof(int);
+    w.n_tasks = (int*)b; b += 16;
+    w.task = (int2*)b; b += p * (size_t)((n_hyp + 63) / 64) * sizeof(int2);
     w.list = (unsigned short*)b;
     return w;
 }
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     double* xn = w.xn + (size_t)pair * a.cap * 4;
     float* px = w.px + (size_t)pair * a.cap * 4;
     int* qidx = w.qidx + (size_t)pair * a.cap;
-    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; w.bound[pair] = 0x7F800000u; }
+    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; w.bound[pair] = 0x7F800000u; if (pair == 0) *w.n_tasks = 0; }
     __syncthreads();
     if (a.d_p1) {  // explicit correspondences
         int m = a.m_fixed;
@@ -512,14 +517,24 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_compact(TwoViewArgs a, TvWork w
         }
     }
     __syncthreads();
-    if (tid == 0) w.n_alive[pair] = s_cnt;
+    // one task per 64 survivors, appended to a launch-wide dense table: k_tv_score's workgroup t takes task t, so the busy
+    // wavefronts are the FIRST ones of its grid and spread evenly over the chip (the empty tail exits at once)
+    __shared__ int s_tbase;
+    const int ntask = (s_cnt + 63) / 64;
+    if (tid == 0) {
+        w.n_alive[pair] = s_cnt;
+        s_tbase = ntask ? atomicAdd(w.n_tasks, ntask) : 0;
+    }
+    __syncthreads();
+    for (int j = tid; j < ntask; j += TV_BLOCK) w.task[s_tbase + j] = make_int2(pair, j * 64);
 }
 
 __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
-    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= *w.n_tasks) return;
+    const int2 tk = w.task[blockIdx.x];
+    const int pair = tk.x, t0 = tk.y;
     const int total = w.n_alive[pair];
-    const int t0 = blockIdx.x * 64;
-    if (t0 >= total) return;
     const int m = w.m[pair];
     const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
     const double thr2 = thr * thr;
@@ -869,7 +884,7 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged);
     if (staged) {
         hipLaunchKernelGGL(k_tv_compact, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
-        hipLaunchKernelGGL(k_tv_score, dim3((a.n_hyp + 63) / 64, a.n_pairs), dim3(64), 0, c->stream, a, w);
+        hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64), 0, c->stream, a, w);
     }
     hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
     HIPCHK(c, hipGetLastError());
