@@ -87,13 +87,16 @@ def test_map_initializer_like_test_map_initializer_py():
     assert ini.initialization_done and ini.current_frame_keypoints is kp2
 
 
-def test_batched_device_mode_equals_host_api():
+# nb = 4: plain workgroup indexing; nb = 16 and 256 (BASELINE config 3, sampled): multiples of 8 take the XCD-affine re-indexing
+@pytest.mark.parametrize("nb,check", [(4, None), (16, None), (256, (0, 1, 100, 254, 255))])
+def test_batched_device_mode_equals_host_api(nb, check):
     """mo_dev_frontend_batch on frames resident in HBM == per-call host API (extract, match, pose)."""
     import torch
     import vslam_amd as V
-    nb, cap = 4, 2048
+    cap = 2048
     base = np.concatenate([synthetic_frame(31), synthetic_frame(32)], axis=1)
-    frames = np.stack([np.ascontiguousarray(base[:, 4 * i:4 * i + 640]) for i in range(nb)])
+    frames = np.stack([np.ascontiguousarray(base[:, (2 * i) % 640:(2 * i) % 640 + 640]) for i in range(nb)])
+    check = list(range(nb)) if check is None else list(check)
     dev = torch.device("cuda", 0)
     ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -122,14 +125,14 @@ def test_batched_device_mode_equals_host_api():
     assert {"pyramid", "fast_nms", "select_harris", "blur", "angle_rbrief", "match_knn2_ratio", "two_view"} <= set(stages)
     cn = counts.cpu().numpy()
     host = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
-    feats = [host.orb_detect_compute(frames[i], prm)[0] for i in range(nb)]
+    feats = {i: host.orb_detect_compute(frames[i], prm)[0] for i in check}
     kp_np = kps.cpu().numpy().view(np.uint8).reshape(nb, cap, 28)
-    for i in range(nb):
+    for i in check:
         n = len(feats[i][0])
         assert cn[i] == n
         assert np.array_equal(kp_np[i, :n].reshape(-1).view(V.KP_DTYPE), feats[i][0])
         assert np.array_equal(desc[i, :n].cpu().numpy(), feats[i][1])
-    for i in range(nb - 1):
+    for i in [j for j in check if j + 1 in feats]:
         idx, dist, ps = host.match_knn2_ratio(feats[i][1], feats[i + 1][1], 0.75)
         n = cn[i]
         assert np.array_equal(midx[i, :n].cpu().numpy(), idx) and np.array_equal(mdist[i, :n].cpu().numpy(), dist)
