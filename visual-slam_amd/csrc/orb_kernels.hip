@@ -426,7 +426,6 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     };
     {
         uint32_t* wq = s_wq[wv];
-        const unsigned long long lt = (1ull << lane) - 1ull;
         const int nxc = (SW + 63) >> 6;
         int qn = 0;  // wave-uniform queue fill
         // 64-pixel chunks of the scored rows, numbered row-major; each trip takes two of them (chunk c and c + 4) so that
@@ -434,25 +433,30 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
         int ra = 0, ja = wv, rb = 0, jb = wv + 4;
         while (ja >= nxc) { ja -= nxc; ra++; }
         while (jb >= nxc) { jb -= nxc; rb++; }
+        // branch-free: lanes past the last scored column read a clamped (valid) address and are masked out of the result;
+        // the window base sits 3 rows and 3 columns before the pixel so that all five reads use non-negative immediates
         auto compass = [&](int r, int x) -> bool {
-            const uint8_t* p = &s_tile[(r + 3) * TW + 3 + lead + x];
-            const int v = p[0];
-            const int d0 = v - p[3 * TW], d4 = v - p[3], d8 = v - p[-3 * TW], d12 = v - p[-3];
+            const uint8_t* w = &s_tile[r * TW + lead + min(x, SW - 1)];
+            const int v = w[3 * TW + 3];
+            const int d0 = v - w[6 * TW + 3], d4 = v - w[3 * TW + 6], d8 = v - w[3], d12 = v - w[3 * TW];
             // >= 2 of the 4 differences above t  <=>  their second largest > t; >= 2 below -t <=> second smallest < -t
             const int mn_a = min(d0, d4), mx_a = max(d0, d4), mn_b = min(d8, d12), mx_b = max(d8, d12);
             const int second_hi = max(max(min(mx_a, mx_b), mn_a), mn_b);
             const int second_lo = min(min(max(mn_a, mn_b), mx_a), mx_b);
-            return max(second_hi, -second_lo) > t;
+            return (max(second_hi, -second_lo) > t) & (x < SW);
         };
         while (ra < rows + 2) {
             const int xa = (ja << 6) + lane, xb = (jb << 6) + lane;
-            const bool live_b = rb < rows + 2;
-            const bool pa = xa < SW && compass(ra, xa);
-            const bool pb = live_b && xb < SW && compass(rb, xb);
-            const unsigned long long ma = __ballot(pa), mb = __ballot(pb);
+            const bool live_b = rb < rows + 2;  // wave-uniform
+            const unsigned long long ma = __ballot(compass(ra, xa));
+            const unsigned long long mb = live_b ? __ballot(compass(rb, xb)) : 0ull;
             const int na = __popcll(ma);
-            if (pa) wq[qn + __popcll(ma & lt)] = ((uint32_t)ra << 16) | (uint32_t)xa;
-            if (pb) wq[qn + na + __popcll(mb & lt)] = ((uint32_t)rb << 16) | (uint32_t)xb;
+            if ((ma >> lane) & 1ull)
+                wq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] =
+                    ((uint32_t)ra << 16) | (uint32_t)xa;
+            if ((mb >> lane) & 1ull)
+                wq[qn + na + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] =
+                    ((uint32_t)rb << 16) | (uint32_t)xb;
             qn += na + __popcll(mb);
             if (qn >= 128) {  // at most 127 + 128 entries are queued
                 replay::wave_sync();  // queue writes of this wavefront are visible to all its lanes
