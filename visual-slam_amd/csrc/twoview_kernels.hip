@@ -275,16 +275,31 @@ __device__ inline uint64_t splitmix64(uint64_t& s) {
     return z ^ (z >> 31);
 }
 
-// 8 distinct sample indices of hypothesis h (shared definition with oracle/geom_oracle.py)
-__device__ inline void sample8(uint64_t seed, int h, int m, int* idx) {
+// 8 distinct sample indices of hypothesis h (shared definition with oracle/geom_oracle.py): c = splitmix64 % m, redrawn
+// while it repeats an earlier index.  m <= 4096, so the 64-bit remainder is taken exactly with three 32-bit
+// multiply-high reductions instead of a software 64-bit division: with M = floor(2^32 / m), q = mulhi(x, M) is
+// floor(x / m) or one less, so x - q m needs one conditional subtraction; and x = hi 2^32 + lo gives
+// x mod m = ((hi mod m) (2^32 mod m) + lo mod m) mod m with every intermediate below 2^25.
+__device__ __forceinline__ void sample8(uint64_t seed, int h, int m, int (&idx)[8]) {
+    const uint32_t um = (uint32_t)m, q0 = 0xFFFFFFFFu / um, r0 = 0xFFFFFFFFu - q0 * um;
+    const uint32_t M = r0 + 1u == um ? q0 + 1u : q0, c32 = r0 + 1u == um ? 0u : r0 + 1u;  // floor(2^32 / m), 2^32 mod m
+    auto mod32 = [um, M](uint32_t x) {
+        uint32_t r = x - __umulhi(x, M) * um;
+        return r >= um ? r - um : r;
+    };
     uint64_t s = seed + (uint64_t)(h + 1) * 0xD1B54A32D192ED03ull;
+#pragma unroll
     for (int k = 0; k < 8; k++) {
-        while (true) {
-            int c = (int)(splitmix64(s) % (uint64_t)m);
-            bool dup = false;
+        int c;
+        bool dup;
+        do {
+            const uint64_t z = splitmix64(s);
+            c = (int)mod32(mod32((uint32_t)(z >> 32)) * c32 + mod32((uint32_t)z));
+            dup = false;
+#pragma unroll
             for (int j = 0; j < k; j++) dup |= idx[j] == c;
-            if (!dup) { idx[k] = c; break; }
-        }
+        } while (dup);
+        idx[k] = c;
     }
 }
 
