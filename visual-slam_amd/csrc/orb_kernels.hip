@@ -521,11 +521,12 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     int pos = base + incl - cnt;
     uint32_t* out = cand + (size_t)frame * P.cand_stride + lv.cand_off + (size_t)strip * lv.strip_cap;
+    const int rr0 = i0 / lv.bw, xx0 = i0 - rr0 * lv.bw;  // start of this thread's run (same as the NMS loop above)
     while (keep) {
         int j = __ffsll((long long)keep) - 1;
         keep &= keep - 1;
-        int i = i0 + j;
-        int rr = i / lv.bw, xx = i - rr * lv.bw;
+        int rr = rr0, xx = xx0 + j;  // j < 64: the run wraps rows by repeated subtraction, no division per candidate
+        while (xx >= lv.bw) { xx -= lv.bw; rr++; }
         int sc = s_score[(rr + 1) * SW + xx + 1];
         if (pos < lv.strip_cap) out[pos] = ((uint32_t)sc << 24) | ((uint32_t)(y0 + rr) << 12) | (uint32_t)(lv.bx0 + xx);
         pos++;
