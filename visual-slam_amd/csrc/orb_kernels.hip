@@ -364,8 +364,9 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     const int th = rows + 8, gy0 = y0 - 4;
     if (al16) {  // 16 bytes per lane; pitch >= the rounded row end because pitch is a multiple of 16
         const int tw16 = (SW + 6 + lead + 15) >> 4;
+        const uint32_t inv = 0xFFFFFFFFu / (uint32_t)tw16 + 1u;  // i / tw16 == mulhi(i, inv) while i * tw16 < 2^32
         for (int i = tid; i < th * tw16; i += 256) {
-            const int r = i / tw16, c16 = i - r * tw16;
+            const int r = tw16 > 1 ? (int)__umulhi((uint32_t)i, inv) : i, c16 = i - r * tw16;
             *(uint4*)(s_tile + r * TW + 16 * c16) = *(const uint4*)(img + (size_t)(gy0 + r) * lv.pitch + gx0 + 16 * c16);
         }
     } else if (al4) {
