@@ -814,27 +814,46 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
 #define DG 16                 // lanes per keypoint (a quarter of a wavefront)
 #define DK_PER_WG (256 / DG)  // keypoints per 256-thread workgroup
 
-// A ROWS x NDW-dword window whose first column is x0a (a multiple of 4), spread over the DG lanes of a keypoint group:
-// lane gl holds dwords gl, gl + 16, gl + 32, ... of the row-major window.  patch_load only issues the global loads (the
-// registers are consumed later, so the loads of both patches are in flight together); patch_store puts them into LDS.
+// A ROWS x NDW-dword window whose first column is x0a (a multiple of 4), spread over the DG = 16 lanes of a keypoint group
+// so that addresses advance by a constant per step (the kernel is VALU-bound: address arithmetic is what this saves):
+//   part A, dword columns 0..7 : lane gl takes column gl & 7 of row 2 s + (gl >> 3) in step s       (two rows per step)
+//   part B, columns 8..NDW-1   : NDW = 9 : lane gl takes column 8 of row 16 s + gl
+//                                NDW = 11: lane gl takes column 8 + min(gl & 3, 2) of row 4 s + (gl >> 2)
+// patch_load only issues the global loads (the registers are consumed later, so the loads of both patches are in flight
+// together); patch_store puts them into LDS, where the per-step stride is an immediate offset.
+template <int ROWS, int NDW> struct PatchMap {
+    static constexpr int SA = (ROWS + 1) / 2;
+    static constexpr int EC = NDW - 8;            // extra dword columns: 1 or 3
+    static constexpr int RB = EC == 1 ? 16 : 4;   // rows per step of part B
+    static constexpr int SB = (ROWS + RB - 1) / RB;
+    static constexpr int N = SA + SB;
+    static_assert(EC == 1 || EC == 3, "window of 9 or 11 dwords");
+};
+
 template <int ROWS, int NDW, int N>
 __device__ __forceinline__ void patch_load(const uint8_t* img, int pitch, int x0a, int y0, int gl, bool aligned, uint32_t (&reg)[N]) {
-    static_assert(N * DG >= ROWS * NDW && (N - 1) * DG < ROWS * NDW && NDW <= DG && 2 * NDW > DG, "register tile shape");
-    int r = 0, c = gl;
-    if (c >= NDW) { c -= NDW; r = 1; }
+    typedef PatchMap<ROWS, NDW> PM;
+    static_assert(N == PM::N && DG == 16, "register tile shape");
+    const int ra = gl >> 3, ca = gl & 7;
+    const int rb = PM::EC == 1 ? gl : gl >> 2, cb = PM::EC == 1 ? 8 : 8 + min(gl & 3, PM::EC - 1);
     if (aligned) {  // the caller keeps x0a + 4 NDW <= pitch: every dword of the window lies inside its row
         const uint8_t* base = img + (size_t)y0 * pitch + x0a;
-        int off = r * pitch + 4 * c;
+        int off = ra * pitch + 4 * ca;
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            if (k == N - 1) off = min(r, ROWS - 1) * pitch + 4 * c;  // only the last trip can run past the window: re-read a valid dword
-            reg[k] = *(const uint32_t*)(base + off);
-            c += DG - NDW; r += 1; off += pitch + 4 * (DG - NDW);       // advance 16 dwords: one row down and DG - NDW to the right,
-            if (c >= NDW) { c -= NDW; r += 1; off += pitch - 4 * NDW; }  // wrapping once more when that passes the row end
+        for (int st = 0; st < PM::SA; st++) {  // only the last step can run past the window: it re-reads the last row
+            reg[st] = *(const uint32_t*)(base + (st == PM::SA - 1 ? min(2 * st + ra, ROWS - 1) * pitch + 4 * ca : off));
+            off += 2 * pitch;
+        }
+        off = rb * pitch + 4 * cb;
+#pragma unroll
+        for (int st = 0; st < PM::SB; st++) {
+            reg[PM::SA + st] = *(const uint32_t*)(base + (st == PM::SB - 1 ? min(PM::RB * st + rb, ROWS - 1) * pitch + 4 * cb : off));
+            off += PM::RB * pitch;
         }
     } else {
 #pragma unroll 1
         for (int k = 0; k < N; k++) {
+            const int r = k < PM::SA ? 2 * k + ra : PM::RB * (k - PM::SA) + rb, c = k < PM::SA ? ca : cb;
             uint32_t v = 0;
             if (r < ROWS) {
                 const uint8_t* p = img + (size_t)(y0 + r) * pitch + x0a + 4 * c;
@@ -842,22 +861,24 @@ __device__ __forceinline__ void patch_load(const uint8_t* img, int pitch, int x0
                     if (x0a + 4 * c + bq < pitch) v |= (uint32_t)p[bq] << (8 * bq);
             }
             reg[k] = v;
-            c += DG - NDW; r += 1;
-            if (c >= NDW) { c -= NDW; r += 1; }
         }
     }
 }
 
 template <int ROWS, int NDW, int N>
 __device__ __forceinline__ void patch_store(uint8_t* dst, int dpitch, int gl, const uint32_t (&reg)[N]) {
-    int r = 0, c = gl;
-    if (c >= NDW) { c -= NDW; r = 1; }
+    typedef PatchMap<ROWS, NDW> PM;
+    const int ra = gl >> 3, ca = gl & 7;
+    const int rb = PM::EC == 1 ? gl : gl >> 2, cb = PM::EC == 1 ? 8 : 8 + min(gl & 3, PM::EC - 1);
+    uint8_t* da = dst + ra * dpitch + 4 * ca;
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-        if (k < N - 1 || r < ROWS) *(uint32_t*)(dst + r * dpitch + 4 * c) = reg[k];
-        c += DG - NDW; r += 1;
-        if (c >= NDW) { c -= NDW; r += 1; }
-    }
+    for (int st = 0; st < PM::SA; st++)
+        if (st < PM::SA - 1 || 2 * st + ra < ROWS) *(uint32_t*)(da + st * 2 * dpitch) = reg[st];
+    uint8_t* db = dst + rb * dpitch + 4 * cb;
+    const bool own = PM::EC == 1 || (gl & 3) < PM::EC;  // NDW = 11: the fourth lane of a row only duplicated a load
+#pragma unroll
+    for (int st = 0; st < PM::SB; st++)
+        if (own && (st < PM::SB - 1 || PM::RB * st + rb < ROWS)) *(uint32_t*)(db + st * PM::RB * dpitch) = reg[PM::SA + st];
 }
 
 __device__ __forceinline__ int group_sum(int v) {  // sum over the DG lanes of a keypoint group
@@ -934,7 +955,7 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
     const int xr0 = al_raw ? min((x - 15) & ~3, lv.pitch - 36) : (x - 15) & ~3, offr = (x - 15) - xr0;
     // half-widths of the two disc rows of this lane: fetched before the patch loads, whose s_waitcnt they would otherwise share
     const int dsc0 = P.umax[15 - gl], dsc1 = P.umax[min(gl + 1, 15)];
-    uint32_t raw[18], blr[27];
+    uint32_t raw[PatchMap<31, 9>::N], blr[PatchMap<39, 11>::N];
     patch_load<31, 9>(img, lv.pitch, xr0, y - 15, gl, al_raw, raw);
     int offb = 0;
     if (HAS_DESC) {
