@@ -901,8 +901,8 @@ __device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch,
         float fx0 = (float)pt[0], fy0 = (float)pt[1], fx1 = (float)pt[2], fy1 = (float)pt[3];
         int ix0 = __float2int_rn(fx0 * a - fy0 * b), iy0 = __float2int_rn(fx0 * b + fy0 * a);
         int ix1 = __float2int_rn(fx1 * a - fy1 * b), iy1 = __float2int_rn(fx1 * b + fy1 * a);
-        int t0 = patch[(cy + iy0) * ppitch + cx + ix0];
-        int t1 = patch[(cy + iy1) * ppitch + cx + ix1];
+        int t0 = patch[__mul24(cy + iy0, ppitch) + cx + ix0];  // 24-bit multiply-add: full rate, unlike v_mul_lo_u32
+        int t1 = patch[__mul24(cy + iy1, ppitch) + cx + ix1];
         val |= (t0 < t1 ? 1u : 0u) << k;
     }
     return (uint16_t)val;  // little endian: bits 0..7 = byte 2gl, bits 8..15 = byte 2gl+1
