@@ -19,6 +19,7 @@ struct LevelInfo {
     float scale;          // (float)pow((double)scale_factor, L)
     int quota;            // features wanted on this level
     int bx0, by0, bw, bh; // border region [bx0, bx0+bw) x [by0, by0+bh): keypoints allowed here
+    uint32_t inv_bw;      // floor(2^32 / bw) + 1 for bw > 1: i / bw == mulhi(i, inv_bw) while i * bw < 2^32
     int strip_rows;       // rows per FAST strip
     int nstrips;          // strips covering the border region
     int strip_cap;        // entries per strip slot

@@ -268,6 +268,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         blur_off += align_up(v.bpitch * v.h, 256);
         if (v.w <= 2 * et || v.h <= 2 * et) { v.bx0 = v.by0 = et; v.bw = v.bh = 0; }
         else { v.bx0 = et; v.by0 = et; v.bw = v.w - 2 * et; v.bh = v.h - 2 * et; }
+        v.inv_bw = v.bw > 1 ? 0xFFFFFFFFu / (uint32_t)v.bw + 1u : 0u;
         v.strip_rows = MO_STRIP_ROWS;
         while (v.strip_rows > 1 && v.strip_rows * v.bw > 16384) v.strip_rows /= 2;
         if (v.bw > 16384) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide");

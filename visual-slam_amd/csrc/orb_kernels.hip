@@ -483,11 +483,13 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     const int nitems = rows * lv.bw;
     const int ipt = (nitems + 255) / 256;
     const int i0 = tid * ipt;
+    // row of the first pixel of this thread's run: i0 / bw by multiply-high with the plan's reciprocal (exact while i0 * bw < 2^32)
+    const int run_row0 = lv.bw > 1 ? (int)__umulhi((uint32_t)i0, lv.inv_bw) : i0;
     unsigned long long keep = 0;
     {
         // sliding 3-column window over the thread's contiguous run: per pixel 3 new byte reads (the column to the right),
         // keep <=> centre > max(column max left, column max right, up, down) and centre > 0
-        int rr = i0 / lv.bw, xx = i0 - rr * lv.bw;
+        int rr = run_row0, xx = i0 - rr * lv.bw;
         const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
         int cl = max(max((int)s[-SW - 1], (int)s[-1]), (int)s[SW - 1]);   // column x-1
         int up = s[-SW], mid = s[0], dn = s[SW];                            // column x
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     int pos = base + incl - cnt;
     uint32_t* out = cand + (size_t)frame * P.cand_stride + lv.cand_off + (size_t)strip * lv.strip_cap;
-    const int rr0 = i0 / lv.bw, xx0 = i0 - rr0 * lv.bw;  // start of this thread's run (same as the NMS loop above)
+    const int rr0 = run_row0, xx0 = i0 - rr0 * lv.bw;  // start of this thread's run (same as the NMS loop above)
     while (keep) {
         int j = __ffsll((long long)keep) - 1;
         keep &= keep - 1;
