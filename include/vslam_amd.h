@@ -147,6 +147,15 @@ int mo_dev_match_pairs(mo_ctx*, const uint8_t* d_desc, const int32_t* d_counts, 
                        const int32_t* d_tf, int n_pairs, double ratio, int32_t* d_idx, int32_t* d_dist,
                        uint8_t* d_pass);
 
+/* Status of the mo_dev_* calls enqueued since the last mo_dev_status: the kernels never fault on overflow, they clamp and
+ * raise a bit.  Synchronises the context stream, copies the flag word to flags[0] (flags may be NULL; [1..3] reserved, 0)
+ * and clears it.  bit 0 (1): a level's internal keypoint slot overflowed (response ties at the quota cut);
+ * bit 1 (2): a frame produced more keypoints than `cap` - its rows are truncated to cap while d_counts[frame] holds the
+ * number it needed (so d_counts can EXCEED cap: clamp before indexing, or retry with cap >= max(d_counts));
+ * bit 2 (4): more than 4096 local maxima in one cell of mo_orb_grid_good_features.
+ * Returns MO_OK when no bit is set, MO_ERR_CAPACITY otherwise. */
+int mo_dev_status(mo_ctx*, int32_t flags[4]);
+
 /* per-stage device time of the last mo_dev_* call, measured with hipEvents on the context stream.
  * names: NULL-terminated array of stage names owned by the library; ms [n] filled. Returns n stages. */
 int mo_stage_times(mo_ctx*, const char*** names, float* ms, int cap);

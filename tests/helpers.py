@@ -48,3 +48,20 @@ def synthetic_frame(seed, w=640, h=480):
         img[y:y + rh, x:x + rw] = rng.uniform(0, 255)
     img = img + rng.normal(0, 3, size=img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def parallax_frames(nb, seed=31, w=640, h=480, bg_step=2, fg_step=4):
+    """nb frames of a camera translating along x past a two-depth scene: the background pans bg_step px / frame, the
+    foreground patches (where a coarse mask image is bright) fg_step px / frame.  Non-planar, so the essential matrix of
+    consecutive frames is well posed.  uint8 [nb, h, w]."""
+    wide = w + fg_step * nb + 8
+    bg = synthetic_frame(seed, wide, h)
+    fg = synthetic_frame(seed + 1, wide, h)
+    rng = np.random.Generator(np.random.PCG64(seed + 2))
+    cells = rng.uniform(0, 255, size=(h // 60 + 2, wide // 60 + 2))
+    mk = np.kron(cells, np.ones((60, 60)))[:h, :wide] > 150
+    out = np.empty((nb, h, w), np.uint8)
+    for i in range(nb):
+        xb, xf = bg_step * i, fg_step * i
+        out[i] = np.where(mk[:, xf:xf + w], fg[:, xf:xf + w], bg[:, xb:xb + w])
+    return out

@@ -17,14 +17,27 @@ static int check_flags(mo_ctx* c) {
     return MO_OK;
 }
 
+extern "C" int mo_dev_status(mo_ctx* c, int32_t flags[4]) {
+    if (!c) return MO_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int f[4] = {0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(f, c->d_flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (flags) { flags[0] = f[0]; flags[1] = flags[2] = flags[3] = 0; }
+    if (f[0] & 7) return mo_fail(c, MO_ERR_CAPACITY, "a capacity flag was raised by a mo_dev_* call (see mo_dev_status in vslam_amd.h)");
+    return MO_OK;
+}
+
 // device pipeline on frames already resident as dense gray [batch][h][w]
 static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int w, int h, int batch,
-                       mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts, bool fresh_timing) {
+                       mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts, bool host_call) {
     int rc = mo_build_plan(c, p, w, h, batch);
     if (rc) return rc;
     if (cap < 1) return mo_fail(c, MO_ERR_ARG, "cap must be >= 1");
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
-    if (fresh_timing) mo_stage_begin(c);
+    // host calls check the flags themselves before they return; mo_dev_* calls accumulate them until mo_dev_status
+    if (host_call) HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    mo_stage_begin(c);
     if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels))) return rc;
     mo_stage_mark(c, "pyramid");
     // the Gaussian blur only depends on the pyramid: it runs on the aux stream beside FAST + selection
@@ -77,7 +90,13 @@ static int stage_images(mo_ctx* c, const uint8_t* img, int w, int h, int stride,
 
 static int reserve_out(mo_ctx* c, int batch, int cap) {
     if (c->d_kps && c->out_cap >= cap && c->out_batch >= batch) return MO_OK;
-    if (c->d_kps) { hipFree(c->d_kps); hipFree(c->d_desc); hipFree(c->d_counts); c->d_kps = nullptr; }
+    // drop all three and the recorded sizes first: a failed hipMalloc below must not leave a size check that passes
+    // with freed pointers
+    if (c->d_kps) hipFree(c->d_kps);
+    if (c->d_desc) hipFree(c->d_desc);
+    if (c->d_counts) hipFree(c->d_counts);
+    c->d_kps = nullptr; c->d_desc = nullptr; c->d_counts = nullptr;
+    c->out_cap = 0; c->out_batch = 0;
     size_t n = (size_t)batch * cap;
     HIPCHK(c, hipMalloc((void**)&c->d_kps, n * sizeof(mo_keypoint)));
     HIPCHK(c, hipMalloc((void**)&c->d_desc, n * 32));
@@ -237,7 +256,10 @@ extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const ui
     if ((rc = mo_reserve(c, c->d_mq, c->m_q_bytes, qb))) return rc;
     if ((rc = mo_reserve(c, c->d_mt, c->m_t_bytes, tb))) return rc;
     if (n > c->m_n) {
-        if (c->d_midx) { hipFree(c->d_midx); hipFree(c->d_mdist); hipFree(c->d_mpass); }
+        if (c->d_midx) hipFree(c->d_midx);
+        if (c->d_mdist) hipFree(c->d_mdist);
+        if (c->d_mpass) hipFree(c->d_mpass);
+        c->d_midx = nullptr; c->d_mdist = nullptr; c->d_mpass = nullptr; c->m_n = 0;
         HIPCHK(c, hipMalloc((void**)&c->d_midx, n * 2 * sizeof(int32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_mdist, n * 2 * sizeof(int32_t)));
         HIPCHK(c, hipMalloc((void**)&c->d_mpass, n));
@@ -341,7 +363,7 @@ extern "C" int mo_dev_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, cons
     if (!c) return MO_ERR_ARG;
     if (!d_gray || !d_kps || !d_counts) return mo_fail(c, MO_ERR_ARG, "NULL device pointer");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_extract(c, p, d_gray, w, h, batch, d_kps, d_desc, cap, d_counts, true);
+    return run_extract(c, p, d_gray, w, h, batch, d_kps, d_desc, cap, d_counts, false);
 }
 
 extern "C" int mo_dev_match_pairs(mo_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int cap, const int32_t* d_qf,
@@ -366,7 +388,7 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
     if (!c) return MO_ERR_ARG;
     if (!io || !io->d_gray || !io->d_kps || !io->d_desc || !io->d_counts) return mo_fail(c, MO_ERR_ARG, "NULL in mo_batch_io");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, true);
+    int rc = run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, false);
     if (rc) return rc;
     int n_pairs = io->batch - 1;
     if (n_pairs < 1 || !io->d_match_idx) return MO_OK;

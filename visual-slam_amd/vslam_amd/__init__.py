@@ -65,6 +65,7 @@ SIGNATURES = {
     "mo_dev_frontend_batch": (_i, [_vp, _vp, _vp]),
     "mo_dev_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mo_dev_match_pairs": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp]),
+    "mo_dev_status": (_i, [_vp, _vp]),
     "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
     "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dbg_fast_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
@@ -163,6 +164,14 @@ class Context:
 
     def sync(self):
         self._check(self.lib.mo_sync(self.h))
+
+    def dev_status(self):
+        """flag word of the mo_dev_* calls since the last query (0 = nothing overflowed); synchronises the stream"""
+        f = (C.c_int32 * 4)()
+        rc = self.lib.mo_dev_status(self.h, f)
+        if rc not in (MO_OK, MO_ERR_CAPACITY):
+            self._check(rc)
+        return int(f[0])
 
     def stage_times(self):
         names = C.POINTER(C.c_char_p)()
