@@ -61,6 +61,30 @@ def test_fast_nms_candidates(ctx, O, thr):
         assert np.array_equal(got, f), "level %d raster-ordered (x, y, score)" % L
 
 
+@pytest.mark.parametrize("thr", [0, 1, 7])
+def test_fast_nms_on_noise_uses_the_dense_fallback(ctx, O, thr):
+    """Uniform noise: about a third of all pixels are FAST corners, far more per strip than the kernel's corner list holds
+    (FAST_CORNER_CAP), so the non-max suppression takes its dense fallback; thresholds 0 and 1 also cover stored scores
+    of 0 (corner with score 0 is never a candidate)."""
+    import vslam_amd as V
+    rng = np.random.Generator(np.random.PCG64(99 + thr))
+    img = rng.integers(0, 256, size=(200, 320), dtype=np.uint8)
+    img[40:90, 100:260] = rng.integers(100, 104, size=(50, 160), dtype=np.uint8)  # a low-contrast patch: scores near the threshold
+    p, o = _prm(V, O, V.ORDER_LIBSTDCXX, fast_threshold=thr, nlevels=3)
+    lw, lh, _, _ = O.levels(320, 200, o)
+    for L in range(3):
+        lvl = O.pyramid_level(img, o, L)
+        f = O.fast_level(lvl, thr)
+        f = f[(f[:, 0] >= 31) & (f[:, 0] < lw[L] - 31) & (f[:, 1] >= 31) & (f[:, 1] < lh[L] - 31)]
+        got = ctx.dbg_fast_level(img, p, L)
+        assert len(got) == len(f) > 0, "level %d count" % L
+        assert np.array_equal(got, f), "level %d raster-ordered (x, y, score)" % L
+    O.lib().orc_set_variant(0, 0)  # libstdc++ order, like p
+    (k, d), = ctx.orb_detect_compute(img, p)
+    ek, ed = O.detect_and_compute(img, o)
+    assert np.array_equal(k, ek) and np.array_equal(d, ed)
+
+
 def _retain_cases():
     rng = np.random.default_rng(5)
     cases = []

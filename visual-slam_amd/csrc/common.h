@@ -58,7 +58,8 @@ struct mo_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    bool match_mfma = false;   // VSLAM_AMD_MATCHER=mfma: opt-in matrix-core matcher (default: XOR + popcount on the vector ALU)
+    int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in
+                               // matrix-core matcher, 2 "scalar" round-1 kernel (train descriptors through scalar loads)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_aux0 = nullptr, ev_aux1 = nullptr;

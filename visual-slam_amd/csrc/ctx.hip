@@ -60,7 +60,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess)
             hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     }
-    if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mfma = std::strcmp(e, "mfma") == 0;
+    if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
     if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] == '1';
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);

@@ -101,6 +101,99 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Default path since round 2: the same XOR + popcount + packed-key fold, but the train descriptors are staged through LDS.
+// A workgroup copies tiles of ML_TILE train descriptors (4 KB, one 16-byte load per thread, register-staged and
+// double-buffered so the next tile's global load is in flight during the current tile's compute; one barrier per tile)
+// and every wavefront reads them back with wave-uniform (broadcast) ds_read_b128: two LDS instructions per train descriptor
+// next to 38 vector instructions, in-order returns (counted lgkmcnt waits, reads issued several descriptors ahead).
+// k_match above takes them through scalar loads instead: those return out of order, every trip waited for all of them
+// (lgkmcnt(0)) with nothing in flight, and the kernel sat at 0.42 of the vector issue rate (profiles/r01_sq_counters).
+#define ML_THREADS 256
+#define ML_Q 2
+#define ML_PER_BLOCK (ML_THREADS * ML_Q)
+#define ML_TILE 128  // train descriptors per tile: 256 threads x 16 B
+
+__global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restrict__ qbase, const uint8_t* __restrict__ tbase,
+                                                          size_t q_stride, size_t t_stride, const int32_t* __restrict__ counts,
+                                                          const int32_t* __restrict__ qf, const int32_t* __restrict__ tf,
+                                                          int nq_fixed, int nt_fixed, int out_stride, double ratio,
+                                                          int32_t* __restrict__ oidx, int32_t* __restrict__ odist,
+                                                          uint8_t* __restrict__ opass) {
+    __shared__ __attribute__((aligned(16))) uint4 s_t[2][ML_TILE * 2 + 4];  // + one look-ahead group past the last descriptor
+    const int pair = blockIdx.y, tid = threadIdx.x;
+    const int qfr = qf ? qf[pair] : pair, tfr = tf ? tf[pair] : pair;
+    const int nq = counts ? min(counts[qfr], out_stride) : nq_fixed;
+    const int nt = counts ? min(counts[tfr], out_stride) : nt_fixed;
+    if (blockIdx.x * ML_PER_BLOCK >= nq) return;  // uniform over the workgroup
+    const uint4* q = (const uint4*)(qbase + (size_t)qfr * q_stride);
+    const uint4* t = (const uint4*)(tbase + (size_t)tfr * t_stride);
+    uint32_t a[ML_Q][8], k0[ML_Q], k1[ML_Q];
+#pragma unroll
+    for (int m = 0; m < ML_Q; m++) {
+        const int qi = min(blockIdx.x * ML_PER_BLOCK + m * ML_THREADS + tid, nq - 1);
+        const uint4 lo = q[(size_t)qi * 2], hi = q[(size_t)qi * 2 + 1];
+        a[m][0] = lo.x; a[m][1] = lo.y; a[m][2] = lo.z; a[m][3] = lo.w;
+        a[m][4] = hi.x; a[m][5] = hi.y; a[m][6] = hi.z; a[m][7] = hi.w;
+        k0[m] = KEY_NONE; k1[m] = KEY_NONE;
+    }
+    const int ntile = (nt + ML_TILE - 1) / ML_TILE;
+    const int n16 = nt * 2;  // 16-byte pieces of the train set
+    if (ntile > 0) s_t[0][tid] = tid < n16 ? t[tid] : make_uint4(0, 0, 0, 0);
+    // the query registers are complete HERE: otherwise their vmcnt wait lands inside the tile loop and, counting in issue
+    // order, would also wait for the next tile's prefetch on every trip
+#pragma unroll
+    for (int m = 0; m < ML_Q; m++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) asm volatile("" : "+v"(a[m][k]));
+    __syncthreads();
+    for (int tile = 0; tile < ntile; tile++) {
+        const bool more = tile + 1 < ntile;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (more) {
+            const int i = (tile + 1) * ML_TILE * 2 + tid;
+            if (i < n16) nxt = t[i];
+        }
+        const uint4* s = s_t[tile & 1];
+        const int j0 = tile * ML_TILE, n = min(ML_TILE, nt - j0);
+        auto fold = [&](const uint4& b0, const uint4& b1, int j) {  // j: wave-uniform train index
+            const uint32_t b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t d[ML_Q];
+#pragma unroll
+            for (int m = 0; m < ML_Q; m++) d[m] = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+#pragma unroll
+                for (int m = 0; m < ML_Q; m++) d[m] = bcnt_acc(a[m][k] ^ b[k], d[m]);
+#pragma unroll
+            for (int m = 0; m < ML_Q; m++) {
+                const uint32_t key = (d[m] << 20) | (uint32_t)j;
+                k1[m] = med3_u32(k0[m], k1[m], key);  // k0 <= k1: new second-best = median, new best = minimum
+                k0[m] = min(k0[m], key);
+            }
+        };
+        // groups of two descriptors with one group of look-ahead: the broadcast reads of group g+1 are in flight while
+        // group g is folded (reads past the last descriptor stay inside the padded buffer and are never folded)
+        uint4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
+        int j = 0;
+#pragma unroll 2
+        for (; j + 2 <= n; j += 2) {
+            const uint4 n0 = s[2 * j + 4], n1 = s[2 * j + 5], n2 = s[2 * j + 6], n3 = s[2 * j + 7];
+            fold(c0, c1, j0 + j);
+            fold(c2, c3, j0 + j + 1);
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        if (j < n) fold(c0, c1, j0 + j);
+        if (more) s_t[(tile + 1) & 1][tid] = nxt;
+        __syncthreads();  // the buffer written here was last read before the previous barrier
+    }
+#pragma unroll
+    for (int m = 0; m < ML_Q; m++) {
+        const int qi = blockIdx.x * ML_PER_BLOCK + m * ML_THREADS + tid;
+        if (qi < nq) emit_match_key(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Opt-in matrix-core path (environment VSLAM_AMD_MATCHER=mfma when the context is created; same results bit for bit).
 // The 2000 x 2000 x 256-bit distance table of a pair is a GEMM over +-1 vectors: with every
 // descriptor bit expanded to the int8 value +127 (set) or -127 (clear), a.b = 16129 * (256 - 2 * hamming).  The
@@ -257,10 +350,18 @@ int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t
     if (nq_max <= 0) return MO_OK;
     if ((d_counts ? out_stride : nt_fixed) >= (1 << 20)) return mo_fail(c, MO_ERR_UNSUPPORTED, "more than 2^20-1 train descriptors");
     const int nt_max = d_counts ? out_stride : nt_fixed;
-    if (c->match_mfma && nt_max <= MM_MAX_TRAIN) {
+    if (c->match_mode == 1 && nt_max <= MM_MAX_TRAIN) {
         dim3 grid((nq_max + MM_QPB - 1) / MM_QPB, n_pairs);
         hipLaunchKernelGGL(k_match_mfma, grid, dim3(MM_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf,
                            d_tf, nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
+        HIPCHK(c, hipGetLastError());
+        return MO_OK;
+    }
+    const bool al16 = ((((size_t)d_q) | ((size_t)d_t) | q_stride | t_stride) & 15) == 0;
+    if (c->match_mode != 2 && al16) {  // default: LDS-staged train tiles
+        dim3 grid((nq_max + ML_PER_BLOCK - 1) / ML_PER_BLOCK, n_pairs);
+        hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf, d_tf,
+                           nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
         HIPCHK(c, hipGetLastError());
         return MO_OK;
     }

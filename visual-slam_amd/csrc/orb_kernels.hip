@@ -325,8 +325,27 @@ __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_ele
 //  1. the strip's pixels (+4 rows / +3 columns of halo) are staged in LDS with aligned dword loads
 //  2. FAST-9 score of every pixel of the strip and its 1-px ring -> u8 score band in LDS (0 = no corner);
 //     work is dealt to the 4 wavefronts in (row, 64-column) units
-//  3. 3x3 non-max suppression + border filter + raster-ordered compaction: each thread owns a contiguous run of
-//     the row-major strip, a block scan of the per-thread popcounts gives the output slot
+//  3. 3x3 non-max suppression + border filter + raster-ordered compaction.  Only pixels with a non-zero score (about 7 %
+//     on textured frames) can be kept, so phase 2b also lists them (bounded LDS list); after the barrier one lane per
+//     LISTED corner compares it with its 8 neighbours and sets its bit in a row-major bitmap of the strip, and the
+//     compaction walks the bitmap words (popcount -> block scan -> emit in raster order).  A strip with more corners than
+//     the list holds (noise at threshold 0) falls back to a dense scan of the score band that fills the same bitmap.
+// 16-bit VOP2 forms (values in the low half of a VGPR): on gfx950 v_sub_u16 / v_min_i16 / v_max_i16 issue at the full
+// vector rate while v_min_i32 / v_max_i32 and every packed (VOP3P) form take twice as long (tools/ubench.hip)
+__device__ __forceinline__ int sub16(int a, int b) { int r; asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int min16(int a, int b) { int r; asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ int max16(int a, int b) { int r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// lane mask of (short)a > (short)b: the compare writes the wave-wide mask directly (inactive lanes read as 0)
+__device__ __forceinline__ unsigned long long ballot_gt16(int a, int b) {
+    unsigned long long m;
+    asm("v_cmp_gt_i16 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+
+#define FAST_CORNER_CAP 896   // listed corners per strip (typical: 300); more -> dense fallback
+#define FAST_KEEP_WORDS 512   // strip_rows * bw <= 16384 candidate positions (mo_build_plan)
+#define FAST_STACK 384        // u16 entries per wavefront: two stacks of <= 191
+
 template <int TW>  // LDS tile pitch: a compile-time constant so the 16 circle reads use immediate offsets
 __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
@@ -350,7 +369,14 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     uint8_t* s_score = smem;            // (R+2) rows x SW
     uint8_t* s_tile = smem + score_bytes;
     __shared__ int s_wsum[4];
-    __shared__ uint32_t s_wq[4][256];  // per-wavefront queue of pixels that pass the compass pre-test
+    // per-wavefront stacks of the pixels that pass the compass pre-test (row << 12 | column): the darker-arc candidates grow
+    // up from [0], the brighter-arc candidates down from [FAST_STACK - 1]; each holds <= 63 + 128 entries
+    __shared__ __attribute__((aligned(16))) uint16_t s_wq[4][FAST_STACK];
+    __shared__ uint16_t s_corner[FAST_CORNER_CAP];  // band positions (row * SW + column) of the pixels with a non-zero score
+    __shared__ int s_ncorner;
+    // bit (rr * bw + xx) set <=> border-region pixel survives the 3x3 NMS; overlays the stacks, which are dead by then
+    uint32_t* const s_keep = (uint32_t*)&s_wq[0][0];
+    static_assert(sizeof(uint16_t) * 4 * FAST_STACK >= 4 * FAST_KEEP_WORDS, "bitmap overlays the stacks");
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int t = P.fast_threshold;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -384,90 +410,93 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
         }
     }
     for (int i = tid; i < ((rows + 2) * SW + 3) >> 2; i += 256) ((uint32_t*)s_score)[i] = 0;  // score 0 unless phase 2b says otherwise
+    if (tid == 0) s_ncorner = 0;
     __syncthreads();
 
     // ---- 2. scores.
     // 2a (every pixel, 5 LDS reads): a 9-arc of the 16-circle always contains >= 2 of the 4 compass pixels, so a pixel
-    //     with fewer than 2 compass pixels darker than v - t AND fewer than 2 brighter than v + t cannot be a corner:
-    //     score 0.  Survivors are appended to a small per-wavefront LDS queue (ballot + prefix popcount).
-    // 2b (survivors only, whenever 128 are queued): with lo = max over arcs of min(d over the 9-arc) and hi = min over
-    //     arcs of max(d over the arc), corner <=> max(lo, -hi) > t and cornerScore = max(t, lo, -hi) - 1.  Each lane scores
-    //     TWO queued pixels with packed 16-bit min/max networks (v_pk_sub/min/max_i16): test and score in one
-    //     branch-free pass over full wavefronts.
+    //     with fewer than 2 compass differences above t AND fewer than 2 below -t cannot be a corner: score 0.  Which of
+    //     the two holds also fixes the ONLY polarity the pixel can be a corner with (two 9-arcs of a 16-circle overlap, so a
+    //     pixel cannot have both a darker and a brighter arc): survivors are appended to a per-wavefront LDS stack with that
+    //     polarity (ballot + prefix popcount); the rare pixel that passes both tests is pushed once per polarity.
+    // 2b (survivors only, 64 at a time off the top of the stack): one-sided score L = max over the 16 arcs of min(d' over
+    //     the 9-arc), d' = +-(centre - circle pixel) by polarity; corner <=> L > t, cornerScore = L - 1 (the other polarity
+    //     cannot exceed -L).  One pixel per lane, 16-bit VOP2 min/max/sub: measured on MI355X (tools/ubench.hip) these issue
+    //     at 2.3 cycles per wavefront, twice the rate of the packed (v_pk_*) and 32-bit min/max forms.
     typedef const volatile __attribute__((address_space(3))) uint8_t lds_cvu8;  // volatile: byte reads stay separate
-    auto score_pair = [&](uint32_t e0, uint32_t e1) {  // queue entry = row << 16 | column
-        const int r0 = e0 >> 16, x0 = e0 & 0xFFFF, r1 = e1 >> 16, x1 = e1 & 0xFFFF;
-        const int pos0 = r0 * SW + x0, pos1 = r1 * SW + x1;
-        lds_cvu8* p = (lds_cvu8*)&s_tile[(r0 + 3) * TW + x0 + 3 + lead];
-        lds_cvu8* q = (lds_cvu8*)&s_tile[(r1 + 3) * TW + x1 + 3 + lead];
-        const s16x2 v = {(short)p[0], (short)q[0]};
-        s16x2 d[16];
-#define FAST_PAIR(k, o) d[k] = v - (s16x2){(short)p[o], (short)q[o]};
-        FAST_PAIR(0, 3 * TW)        FAST_PAIR(1, 3 * TW + 1)    FAST_PAIR(2, 2 * TW + 2)    FAST_PAIR(3, TW + 3)
-        FAST_PAIR(4, 3)             FAST_PAIR(5, -TW + 3)       FAST_PAIR(6, -2 * TW + 2)   FAST_PAIR(7, -3 * TW + 1)
-        FAST_PAIR(8, -3 * TW)       FAST_PAIR(9, -3 * TW - 1)   FAST_PAIR(10, -2 * TW - 2)  FAST_PAIR(11, -TW - 3)
-        FAST_PAIR(12, -3)           FAST_PAIR(13, TW - 3)       FAST_PAIR(14, 2 * TW - 2)   FAST_PAIR(15, 3 * TW - 1)
-#undef FAST_PAIR
-        s16x2 mn3[16], mx3[16];
+    const int t_list = max(t, 1);  // a pixel is listed for phase 3 when its stored score (L - 1 for L > t) is non-zero
+    auto score_one = [&](uint32_t e, int flip, bool own) {  // stack entry = row << 12 | column; own: not a filler lane
+        const int r = e >> 12, x = e & 0xFFF;
+        const int pos = r * SW + x;
+        // flip (wave-uniform) = 0xFF: brighter-arc polarity, bytes complemented: (255 - v) - (255 - p) = p - v
+        lds_cvu8* p = (lds_cvu8*)&s_tile[(r + 3) * TW + x + 3 + lead];
+        const int v = (int)p[0] ^ flip;
+        int d[16];
+#define FAST_D(k, o) d[k] = sub16(v, (int)p[o] ^ flip);
+        FAST_D(0, 3 * TW)        FAST_D(1, 3 * TW + 1)    FAST_D(2, 2 * TW + 2)    FAST_D(3, TW + 3)
+        FAST_D(4, 3)             FAST_D(5, -TW + 3)       FAST_D(6, -2 * TW + 2)   FAST_D(7, -3 * TW + 1)
+        FAST_D(8, -3 * TW)       FAST_D(9, -3 * TW - 1)   FAST_D(10, -2 * TW - 2)  FAST_D(11, -TW - 3)
+        FAST_D(12, -3)           FAST_D(13, TW - 3)       FAST_D(14, 2 * TW - 2)   FAST_D(15, 3 * TW - 1)
+#undef FAST_D
+        int mn3[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            mn3[i] = pk_min(d[i], pk_min(d[(i + 1) & 15], d[(i + 2) & 15]));
-            mx3[i] = pk_max(d[i], pk_max(d[(i + 1) & 15], d[(i + 2) & 15]));
-        }
-        s16x2 lo = {-512, -512}, hi = {512, 512};
+        for (int i = 0; i < 16; i++) mn3[i] = min16(d[i], min16(d[(i + 1) & 15], d[(i + 2) & 15]));
+        int L = min16(mn3[0], min16(mn3[3], mn3[6]));
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            lo = pk_max(lo, pk_min(mn3[i], pk_min(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
-            hi = pk_min(hi, pk_max(mx3[i], pk_max(mx3[(i + 3) & 15], mx3[(i + 6) & 15])));
+        for (int i = 1; i < 16; i++) L = max16(L, min16(mn3[i], min16(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
+        const int b = (int)(short)L;
+        if (own && b > t) s_score[pos] = (uint8_t)(b - 1);  // the band is zero-filled; the other polarity of the pixel writes nothing
+        // list the corners for phase 3 (order is irrelevant): one LDS atomic per wavefront call
+        const bool c = own && b > t_list;
+        const unsigned long long m = __ballot(c);
+        if (m) {  // wave-uniform
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncorner, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            const int o = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (c && o < FAST_CORNER_CAP) s_corner[o] = (uint16_t)pos;
         }
-        const s16x2 best = pk_max(lo, -hi);
-        const int b0 = best.x, b1 = best.y;
-        s_score[pos0] = (uint8_t)(b0 > t ? b0 - 1 : 0);
-        s_score[pos1] = (uint8_t)(b1 > t ? b1 - 1 : 0);
     };
     {
-        uint32_t* wq = s_wq[wv];
+        uint16_t* wq = s_wq[wv];
         const int nxc = (SW + 63) >> 6;
-        int qn = 0;  // wave-uniform queue fill
-        // 64-pixel chunks of the scored rows, numbered row-major; each trip takes two of them (chunk c and c + 4) so that
-        // ten independent LDS reads are in flight.  r*, j*, qn are wave-uniform (scalar registers).
+        int qd = 0, qb = 0;  // wave-uniform stack fills (darker-arc / brighter-arc candidates)
+        // 64-pixel chunks of the scored rows, numbered row-major; each trip takes two of them (chunk c and c + 4).
+        // r*, j*, qd, qb are wave-uniform (scalar registers).
         int ra = 0, ja = wv, rb = 0, jb = wv + 4;
         while (ja >= nxc) { ja -= nxc; ra++; }
         while (jb >= nxc) { jb -= nxc; rb++; }
+        const int tv = t, ntv = -t;
         // branch-free: lanes past the last scored column read a clamped (valid) address and are masked out of the result;
-        // the window base sits 3 rows and 3 columns before the pixel so that all five reads use non-negative immediates
-        auto compass = [&](int r, int x) -> bool {
+        // the window base sits 3 rows and 3 columns before the pixel so that all five reads use non-negative immediates.
+        // second largest of the 4 compass differences > t <=> >= 2 of them above t; second smallest < -t <=> >= 2 below -t
+        auto chunk = [&](int r, int j) {
+            const int x = (j << 6) + lane;
+            const int rem = SW - (j << 6);  // scored columns left from this chunk on (wave-uniform, >= 1)
+            const unsigned long long valid = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
             const uint8_t* w = &s_tile[r * TW + lead + min(x, SW - 1)];
             const int v = w[3 * TW + 3];
-            const int d0 = v - w[6 * TW + 3], d4 = v - w[3 * TW + 6], d8 = v - w[3], d12 = v - w[3 * TW];
-            // >= 2 of the 4 differences above t  <=>  their second largest > t; >= 2 below -t <=> second smallest < -t
-            const int mn_a = min(d0, d4), mx_a = max(d0, d4), mn_b = min(d8, d12), mx_b = max(d8, d12);
-            const int second_hi = max(max(min(mx_a, mx_b), mn_a), mn_b);
-            const int second_lo = min(min(max(mn_a, mn_b), mx_a), mx_b);
-            return (max(second_hi, -second_lo) > t) & (x < SW);
+            const int d0 = sub16(v, w[6 * TW + 3]), d4 = sub16(v, w[3 * TW + 6]), d8 = sub16(v, w[3]), d12 = sub16(v, w[3 * TW]);
+            const int mn_a = min16(d0, d4), mx_a = max16(d0, d4), mn_b = min16(d8, d12), mx_b = max16(d8, d12);
+            const int second_hi = max16(max16(min16(mx_a, mx_b), mn_a), mn_b);
+            const int second_lo = min16(min16(max16(mn_a, mn_b), mx_a), mx_b);
+            const unsigned long long md = ballot_gt16(second_hi, tv) & valid;   // centre above >= 2 compass pixels by more than t
+            const unsigned long long mb = ballot_gt16(ntv, second_lo) & valid;  // centre below >= 2 compass pixels by more than t
+            const uint16_t e = (uint16_t)((r << 12) | x);
+            if ((md >> lane) & 1ull) wq[qd + __builtin_amdgcn_mbcnt_hi((unsigned)(md >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)md, 0u))] = e;
+            qd += __popcll(md);
+            if ((mb >> lane) & 1ull)
+                wq[FAST_STACK - 1 - qb - __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = e;
+            qb += __popcll(mb);
         };
         while (ra < rows + 2) {
-            const int xa = (ja << 6) + lane, xb = (jb << 6) + lane;
-            const bool live_b = rb < rows + 2;  // wave-uniform
-            const unsigned long long ma = __ballot(compass(ra, xa));
-            const unsigned long long mb = live_b ? __ballot(compass(rb, xb)) : 0ull;
-            const int na = __popcll(ma);
-            if ((ma >> lane) & 1ull)
-                wq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0u))] =
-                    ((uint32_t)ra << 16) | (uint32_t)xa;
-            if ((mb >> lane) & 1ull)
-                wq[qn + na + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] =
-                    ((uint32_t)rb << 16) | (uint32_t)xb;
-            qn += na + __popcll(mb);
-            if (qn >= 128) {  // at most 127 + 128 entries are queued
-                replay::wave_sync();  // queue writes of this wavefront are visible to all its lanes
-                score_pair(wq[2 * lane], wq[2 * lane + 1]);
-                qn -= 128;
-                const uint32_t c0 = wq[128 + lane], c1 = wq[192 + lane];  // <= 127 left-over entries move to the front
-                replay::wave_sync();
-                if (lane < qn) wq[lane] = c0;
-                if (64 + lane < qn) wq[64 + lane] = c1;
-                replay::wave_sync();
+            chunk(ra, ja);
+            if (rb < rows + 2) chunk(rb, jb);  // wave-uniform
+            if (qd >= 64 || qb >= 64) {
+                replay::wave_sync();  // stack writes of this wavefront are visible to all its lanes
+                while (qd >= 64) { qd -= 64; score_one(wq[qd + lane], 0, true); }
+                while (qb >= 64) { qb -= 64; score_one(wq[FAST_STACK - 1 - qb - lane], 0xFF, true); }
+                replay::wave_sync();  // the entries just read may be overwritten by the next pushes
             }
             ja += 8;
             while (ja >= nxc) { ja -= nxc; ra++; }
@@ -475,42 +504,50 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
             while (jb >= nxc) { jb -= nxc; rb++; }
         }
         replay::wave_sync();
-        if (2 * lane < qn) score_pair(wq[2 * lane], wq[min(2 * lane + 1, qn - 1)]);
+        // wave-uniform tails; lanes past a stack re-read its last entry
+        if (qd > 0) score_one(wq[min(lane, qd - 1)], 0, lane < qd);
+        if (qb > 0) score_one(wq[FAST_STACK - 1 - min(lane, qb - 1)], 0xFF, lane < qb);
     }
     __syncthreads();
+    for (int i = tid; i < FAST_KEEP_WORDS; i += 256) s_keep[i] = 0;  // the stacks are dead: their space becomes the keep bitmap
+    __syncthreads();
 
-    // ---- 3. NMS + border filter + raster-ordered compaction
+    // ---- 3. NMS + border filter on the listed corners -> bitmap -> raster-ordered compaction
     const int nitems = rows * lv.bw;
-    const int ipt = (nitems + 255) / 256;
-    const int i0 = tid * ipt;
-    // row of the first pixel of this thread's run: i0 / bw by multiply-high with the plan's reciprocal (exact while i0 * bw < 2^32)
-    const int run_row0 = lv.bw > 1 ? (int)__umulhi((uint32_t)i0, lv.inv_bw) : i0;
-    unsigned long long keep = 0;
     {
-        // sliding 3-column window over the thread's contiguous run: per pixel 3 new byte reads (the column to the right),
-        // keep <=> centre > max(column max left, column max right, up, down) and centre > 0
-        int rr = run_row0, xx = i0 - rr * lv.bw;
-        const uint8_t* s = &s_score[(rr + 1) * SW + xx + 1];
-        int cl = max(max((int)s[-SW - 1], (int)s[-1]), (int)s[SW - 1]);   // column x-1
-        int up = s[-SW], mid = s[0], dn = s[SW];                            // column x
-        for (int j = 0; j < ipt && i0 + j < nitems; j++) {
-            const int up1 = s[-SW + 1], mid1 = s[1], dn1 = s[SW + 1];       // column x+1
-            const int cr = max(max(up1, mid1), dn1);
-            const int nb = max(max(cl, cr), max(up, dn));
-            if (mid > 0 && mid > nb) keep |= 1ull << j;
-            if (++xx == lv.bw) {  // the run wraps to the next row of the strip: restart the window
-                xx = 0; rr++;
-                s = &s_score[(rr + 1) * SW + 1];
-                cl = max(max((int)s[-SW - 1], (int)s[-1]), (int)s[SW - 1]);
-                up = s[-SW]; mid = s[0]; dn = s[SW];
-            } else {
-                cl = max(max(up, mid), dn);
-                up = up1; mid = mid1; dn = dn1;
-                s++;
+        const int nc = s_ncorner;  // block-uniform
+        const uint32_t inv_sw = 0xFFFFFFFFu / (uint32_t)SW + 1u;  // p / SW == mulhi(p, inv_sw) while p * SW < 2^32 (p < 65536, SW <= 16386)
+        auto nms_at = [&](int p) {  // band position p = r * SW + x: keep <=> inside the border region and strictly above its 8 neighbours
+            const int r = (int)__umulhi((uint32_t)p, inv_sw), x = p - r * SW;
+            if (r < 1 || r > rows || x < 1 || x > lv.bw) return;
+            const uint8_t* c = &s_score[p];
+            const int mid = c[0];
+            const int nb = max(max(max((int)c[-SW - 1], (int)c[-SW]), max((int)c[-SW + 1], (int)c[-1])),
+                               max(max((int)c[1], (int)c[SW - 1]), max((int)c[SW], (int)c[SW + 1])));
+            if (mid > nb) {
+                const int i = (r - 1) * lv.bw + (x - 1);
+                atomicOr(&s_keep[i >> 5], 1u << (i & 31));
+            }
+        };
+        if (nc <= FAST_CORNER_CAP) {
+            for (int k = tid; k < nc; k += 256) nms_at(s_corner[k]);
+        } else {  // the list overflowed: dense scan of the score band, one dword (4 positions) per lane and trip
+            const int nband = (rows + 2) * SW;
+            for (int k = tid; 4 * k < nband; k += 256) {
+                uint32_t w = ((const uint32_t*)s_score)[k];
+#pragma unroll
+                for (int bq = 0; bq < 4; bq++)
+                    if (((w >> (8 * bq)) & 0xFFu) && 4 * k + bq < nband) nms_at(4 * k + bq);
             }
         }
     }
-    int cnt = __popcll(keep);
+    __syncthreads();
+    const int nwords = (nitems + 31) >> 5, wpt = (nwords + 255) >> 8;  // wpt <= 2
+    uint32_t kw[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+        if (q < wpt && tid * wpt + q < nwords) kw[q] = s_keep[tid * wpt + q];
+    const int cnt = __popc(kw[0]) + __popc(kw[1]);
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -521,18 +558,21 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict_
     __syncthreads();
     int base = 0;
     for (int k = 0; k < wv; k++) base += s_wsum[k];
-    int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
     int pos = base + incl - cnt;
     uint32_t* out = cand + (size_t)frame * P.cand_stride + lv.cand_off + (size_t)strip * lv.strip_cap;
-    const int rr0 = run_row0, xx0 = i0 - rr0 * lv.bw;  // start of this thread's run (same as the NMS loop above)
-    while (keep) {
-        int j = __ffsll((long long)keep) - 1;
-        keep &= keep - 1;
-        int rr = rr0, xx = xx0 + j;  // j < 64: the run wraps rows by repeated subtraction, no division per candidate
-        while (xx >= lv.bw) { xx -= lv.bw; rr++; }
-        int sc = s_score[(rr + 1) * SW + xx + 1];
-        if (pos < lv.strip_cap) out[pos] = ((uint32_t)sc << 24) | ((uint32_t)(y0 + rr) << 12) | (uint32_t)(lv.bx0 + xx);
-        pos++;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint32_t bits = kw[q];
+        while (bits) {
+            const int j = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int i = (tid * wpt + q) * 32 + j;
+            const int rr = lv.bw > 1 ? (int)__umulhi((uint32_t)i, lv.inv_bw) : i, xx = i - rr * lv.bw;  // exact while i * bw < 2^32
+            const int sc = s_score[(rr + 1) * SW + xx + 1];
+            if (pos < lv.strip_cap) out[pos] = ((uint32_t)sc << 24) | ((uint32_t)(y0 + rr) << 12) | (uint32_t)(lv.bx0 + xx);
+            pos++;
+        }
     }
     if (tid == 0) strip_cnt[(size_t)frame * P.strips_per_frame + lv.strip_base + strip] = min(total, lv.strip_cap);
 }
@@ -541,7 +581,7 @@ template <int TW> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, in
     const Plan& P = c->plan;
     size_t lds = score_bytes + (size_t)(max_rows + 8) * TW + 16;
     if (lds > 128 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
-    const unsigned bit = TW == 704 ? 1u : TW == 1344 ? 2u : TW == 2112 ? 4u : 8u;
+    const unsigned bit = TW == 704 ? 1u : TW == 1344 ? 2u : TW == 2112 ? 4u : TW == 608 ? 32u : 8u;
     if (!(c->lds_attr_done & bit)) {
         HIPCHK(c, hipFuncSetAttribute((const void*)k_fast<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         c->lds_attr_done |= bit;
@@ -563,6 +603,7 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
         max_rows = std::max(max_rows, v.strip_rows);
     }
     if (P.strips_per_frame < 1) return MO_OK;
+    if (tw_need <= 608) return launch_fast_tw<608>(c, d_gray, batch, score_bytes, max_rows);  // 640-wide frames: 8 workgroups per CU
     if (tw_need <= 704) return launch_fast_tw<704>(c, d_gray, batch, score_bytes, max_rows);
     if (tw_need <= 1344) return launch_fast_tw<1344>(c, d_gray, batch, score_bytes, max_rows);
     if (tw_need <= 2112) return launch_fast_tw<2112>(c, d_gray, batch, score_bytes, max_rows);

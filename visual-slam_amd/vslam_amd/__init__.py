@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "libvslam_amd.so")
+# VSLAM_AMD_LIB: another build of the same library (A/B timing of kernel variants); default: the in-tree build
+LIB_PATH = os.environ.get("VSLAM_AMD_LIB") or os.path.join(_PKG_ROOT, "libvslam_amd.so")
 
 MO_OK, MO_ERR_ARG, MO_ERR_HIP, MO_ERR_CAPACITY, MO_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 ORDER_LIBSTDCXX, ORDER_MSVC = 0, 1
