@@ -108,6 +108,18 @@ int mo_init_two_view(mo_ctx*, const float* p1, const float* p2, int m, const dou
                      uint8_t* ransac_inlier /* [m] findEssentialMat mask, may be NULL */, uint8_t* inlier, float* X,
                      int* n_good);
 
+/* One tracking step of Tracker._track_from_last_frame (tracker.py:214-254) for a single frame pair, host in / host out:
+ * matcher.match(prev, cur) -> displacement filter (matcher.py:109-142, frac = 0.02 of (w + h) / 2) -> 2 x median distance
+ * filter (matcher.py:144-169) -> cv2.findEssentialMat(RANSAC, 0.999, thr_px = 1.0) -> cv2.recoverPose, all on the device.
+ * kps1/desc1 = previous frame (query), kps2/desc2 = current frame (train); ratio <= 0 disables the ratio test.
+ * sel_idx [min(n1, 4096)][2] (queryIdx, trainIdx) and sel_dist receive the kept matches in the reference's order (ascending
+ * distance, ties in query order), n_sel their number; inlier [n_sel] the recoverPose mask per kept match.  With fewer than 8
+ * kept matches (tracker.py:234) R, t, E are NaN and n_inliers = 0. */
+int mo_track_pair(mo_ctx*, const mo_keypoint* kps1, int n1, const uint8_t* desc1, const mo_keypoint* kps2, int n2,
+                  const uint8_t* desc2, int w, int h, double ratio, double disp_frac, const double K[9], double thr_px,
+                  int n_hyp, uint64_t seed, double R[9], double t[3], double E[9], int32_t* sel_idx, int32_t* sel_dist,
+                  int* n_sel, uint8_t* inlier, int* n_inliers);
+
 /* Replaces cv2.triangulatePoints(P1, P2, pts1, pts2)   (utils.py:56-60): per-point 4x4 DLT null vector.
  * P1, P2 row-major 3x4 f64; p1, p2 [n][2] f32; X4 [n][4] f32 homogeneous (unit norm, sign arbitrary -
  * the reference divides by w, utils.py:62-70). */
@@ -135,7 +147,20 @@ typedef struct {
     double* d_pose;         /* [batch-1][12] R (9) then t (3); may be NULL when n_hyp == 0 */
     float* d_points;        /* [batch-1][cap][3] triangulated points per query keypoint (NaN = none) */
     int32_t* d_n_points;    /* [batch-1] number of valid map points per pair */
+    /* ---- appended in round 2 (zero-initialise the struct: all of these are optional) ---- */
+    int32_t mode;           /* MO_MODE_INIT (0): two-view stage on the ratio-test survivors in query order (MapInitializer.initialize);
+                               MO_MODE_TRACK (1): Tracker._track_from_last_frame (tracker.py:214-254) - displacement filter
+                               (matcher.py:109-142) and 2 x median distance filter (matcher.py:144-169) behind the matcher, then the
+                               two-view stage on the kept matches in the reference's order (tracker.py:242 passes thr_px = 1.0) */
+    double disp_frac;       /* MO_MODE_TRACK: threshold_percent of filter_matches_by_geometric_distance (tracker.py:219: 0.02) */
+    int32_t* d_sel_idx;     /* MO_MODE_TRACK: [batch-1][cap][2] (queryIdx, trainIdx) of the kept matches, ascending distance */
+    int32_t* d_sel_dist;    /* MO_MODE_TRACK: [batch-1][cap] their Hamming distances; may be NULL */
+    int32_t* d_sel_n;       /* MO_MODE_TRACK: [batch-1] number of kept matches */
+    uint8_t* d_pose_mask;   /* either mode, may be NULL: [batch-1][cap] recoverPose mask per QUERY keypoint */
 } mo_batch_io;
+
+#define MO_MODE_INIT 0
+#define MO_MODE_TRACK 1
 
 /* One pass of the hot path over a batch: extract every frame, match consecutive frames, two-view pose +
  * map points per pair.  Enqueues on the context stream; call mo_sync (or sync the stream) before reading. */

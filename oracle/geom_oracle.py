@@ -197,3 +197,38 @@ def synthetic_two_view(seed=4096, n=2000, outlier_frac=0.3, K=None, w=640, h=480
     no = int(out.sum())
     p2[out] = np.stack([rng.uniform(0, w, no), rng.uniform(0, h, no)], axis=1).astype(np.float32)
     return dict(K=K, p1=p1, p2=p2, R=R, t=t.reshape(3, 1), X=X, outlier=out)
+
+
+# ---- tracking step (reference src/orbslam2/tracker.py:214-254) -------------------------------------------------------
+def track_select(xy1, xy2, idx, dist, keep, width, height, frac=0.02):
+    """The two match filters Tracker._track_from_last_frame applies between matcher.match and findEssentialMat:
+      matcher.py:109-142  filter_matches_by_geometric_distance: keep hypot(pt2 - pt1) <= ((w + h) / 2) * frac   (Python floats)
+      matcher.py:144-169  filter_matches_by_distance: stable sort by distance, keep distance < 2 * np.median(distances)
+    xy1 / xy2: (N, 2) float32 keypoint coordinates of the previous / current frame; idx, dist, keep: knn output of
+    matcher.match(prev, cur) (query = previous frame).  -> (queryIdx, trainIdx, distance) arrays in the reference's order."""
+    import math
+    q = np.nonzero(np.asarray(keep))[0]
+    t = np.asarray(idx)[q, 0]
+    d = np.asarray(dist)[q, 0]
+    limit = ((width + height) / 2.0) * frac
+    ok = np.array([math.hypot(float(xy2[b, 0]) - float(xy1[a, 0]), float(xy2[b, 1]) - float(xy1[a, 1])) <= limit
+                   for a, b in zip(q, t)], bool)
+    q, t, d = q[ok], t[ok], d[ok]
+    if len(q) == 0:
+        return q, t, d
+    order = np.argsort(d, kind="stable")  # Python's sorted() is stable: ties stay in query order
+    q, t, d = q[order], t[order], d[order]
+    thr = float(np.median(d.astype(np.float64))) * 2.0
+    k = d.astype(np.float64) < thr
+    return q[k], t[k], d[k]
+
+
+def track_pair(xy1, xy2, idx, dist, keep, K, width, height, frac=0.02, thr_px=1.0, n_hyp=4096, seed=4096, pair=0):
+    """tracker.py:214-254: filters above, then E-RANSAC at 1 px and recoverPose on the selected matches (in that order)."""
+    q, t, d = track_select(xy1, xy2, idx, dist, keep, width, height, frac)
+    out = dict(sel_q=q, sel_t=t, sel_d=d, R=None, t=None, pose_mask=np.zeros(len(q), bool), n_good=0)
+    if len(q) < 8:  # tracker.py:234
+        return out
+    r = init_two_view(np.asarray(xy1, np.float32)[q], np.asarray(xy2, np.float32)[t], K, thr_px, n_hyp, seed, pair)
+    out.update(R=r["R"], t=r["t"], E=r["E"], pose_mask=r["pose_mask"], ransac_mask=r["ransac_mask"], n_good=r["n_good"], X=r["X"])
+    return out

@@ -337,6 +337,89 @@ extern "C" int mo_init_two_view(mo_ctx* c, const float* p1, const float* p2, int
     return MO_OK;
 }
 
+extern "C" int mo_track_pair(mo_ctx* c, const mo_keypoint* kps1, int n1, const uint8_t* desc1, const mo_keypoint* kps2, int n2,
+                             const uint8_t* desc2, int w, int h, double ratio, double disp_frac, const double K[9], double thr_px,
+                             int n_hyp, uint64_t seed, double R[9], double t[3], double E[9], int32_t* sel_idx, int32_t* sel_dist,
+                             int* n_sel, uint8_t* inlier, int* n_inliers) {
+    if (!c) return MO_ERR_ARG;
+    if (!K || !R || !t || !n_sel || !n_inliers || n1 < 0 || n2 < 0) return mo_fail(c, MO_ERR_ARG, "NULL / negative argument");
+    if (n1 > 4096 || n2 > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "at most 4096 keypoints per frame");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_sel = 0; *n_inliers = 0;
+    for (int i = 0; i < 9; i++) { R[i] = NAN; if (E) E[i] = NAN; }
+    for (int i = 0; i < 3; i++) t[i] = NAN;
+    if (n1 == 0 || n2 == 0) return MO_OK;
+    if (!kps1 || !kps2 || !desc1 || !desc2 || !sel_idx || !inlier) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    const int cap = (std::max(n1, n2) + 15) & ~15;
+    // device layout of a two-frame batch: [kps 2 x cap][desc 2 x cap x 32][counts 2][match idx / dist / pass][sel ...][two-view outputs]
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_kps = take((size_t)2 * cap * sizeof(mo_keypoint)), o_desc = take((size_t)2 * cap * 32), o_cnt = take(2 * sizeof(int32_t)),
+                 o_midx = take((size_t)cap * 2 * sizeof(int32_t)), o_mdist = take((size_t)cap * 2 * sizeof(int32_t)), o_mpass = take(cap),
+                 o_sel = take((size_t)cap * 2 * sizeof(int32_t)), o_seld = take((size_t)cap * sizeof(int32_t)), o_seln = take(sizeof(int32_t)),
+                 o_pose = take(12 * sizeof(double)), o_E = take(9 * sizeof(double)), o_X = take((size_t)cap * 3 * sizeof(float)),
+                 o_inl = take(cap), o_np = take(sizeof(int32_t)), o_qt = take(2 * sizeof(int32_t));
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    mo_keypoint* d_kps = (mo_keypoint*)(b + o_kps);
+    uint8_t* d_desc = b + o_desc;
+    int32_t* d_cnt = (int32_t*)(b + o_cnt);
+    const int32_t cnt[2] = {n1, n2};
+    HIPCHK(c, hipMemcpyAsync(d_kps, kps1, (size_t)n1 * sizeof(mo_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_kps + cap, kps2, (size_t)n2 * sizeof(mo_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_desc, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_desc + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    mo_stage_begin(c);
+    // pair 0 = frame 0 (query) vs frame 1 (train)
+    int32_t* d_qt = (int32_t*)(b + o_qt);
+    const int32_t qt[2] = {0, 1};
+    HIPCHK(c, hipMemcpyAsync(d_qt, qt, sizeof(qt), hipMemcpyHostToDevice, c->stream));
+    if ((rc = match_launch_pairs(c, d_desc, d_desc, (size_t)cap * 32, (size_t)cap * 32, d_cnt, d_qt, d_qt + 1, 0, 0, 1, cap, ratio,
+                                 (int32_t*)(b + o_midx), (int32_t*)(b + o_mdist), b + o_mpass)))
+        return rc;
+    if ((rc = track_select_launch(c, d_kps, d_cnt, d_qt, d_qt + 1, (int32_t*)(b + o_midx), (int32_t*)(b + o_mdist), b + o_mpass, cap, 1,
+                                  w, h, disp_frac, (int32_t*)(b + o_sel), (int32_t*)(b + o_seld), (int32_t*)(b + o_seln))))
+        return rc;
+    TwoViewArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_pairs = 1; a.cap = cap; a.n_hyp = n_hyp;
+    for (int i = 0; i < 9; i++) a.K[i] = K[i];
+    a.thr_px = thr_px; a.seed = seed;
+    a.d_kps = d_kps; a.d_counts = d_cnt; a.d_match_idx = (int32_t*)(b + o_midx); a.d_match_pass = b + o_mpass;
+    a.d_sel = (int32_t*)(b + o_sel); a.d_sel_n = (int32_t*)(b + o_seln);
+    a.d_pose = (double*)(b + o_pose); a.d_E = (double*)(b + o_E); a.d_points = (float*)(b + o_X); a.d_inlier = b + o_inl;
+    a.d_n_points = (int32_t*)(b + o_np);
+    if ((rc = twoview_launch(c, a))) return rc;
+    mo_stage_mark(c, "track_pair");
+    int32_t ns = 0, np = 0;
+    double pose[12], Eh[9];
+    HIPCHK(c, hipMemcpyAsync(&ns, b + o_seln, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&np, b + o_np, sizeof(np), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(pose, b + o_pose, sizeof(pose), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(Eh, b + o_E, sizeof(Eh), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ns = std::min(std::max(ns, 0), cap);
+    *n_sel = ns;
+    if (ns > 0) {
+        std::vector<uint8_t> mask((size_t)cap);
+        HIPCHK(c, hipMemcpyAsync(sel_idx, b + o_sel, (size_t)ns * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (sel_dist) HIPCHK(c, hipMemcpyAsync(sel_dist, b + o_seld, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(mask.data(), b + o_inl, (size_t)cap, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int j = 0; j < ns; j++) inlier[j] = mask[(size_t)sel_idx[2 * j]];  // the pose mask is indexed by query keypoint
+    }
+    if (ns >= 8) {  // tracker.py:234: fewer than 8 matches -> tracking fails (R, t stay NaN)
+        for (int i = 0; i < 9; i++) { R[i] = pose[i]; if (E) E[i] = Eh[i]; }
+        for (int i = 0; i < 3; i++) t[i] = pose[9 + i];
+        *n_inliers = np;
+    } else {
+        std::memset(inlier, 0, (size_t)ns);
+    }
+    return MO_OK;
+}
+
 extern "C" int mo_triangulate_points(mo_ctx* c, const double P1[12], const double P2[12], const float* p1, const float* p2,
                                      int n, float* X4) {
     if (!c) return MO_ERR_ARG;
@@ -410,7 +493,15 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
         for (int i = 0; i < 9; i++) a.K[i] = io->K[i];
         a.thr_px = io->thr_px; a.seed = io->seed;
         a.d_kps = io->d_kps; a.d_counts = io->d_counts; a.d_match_idx = io->d_match_idx; a.d_match_pass = io->d_match_pass;
-        a.d_pose = io->d_pose; a.d_points = io->d_points; a.d_n_points = io->d_n_points;
+        a.d_pose = io->d_pose; a.d_points = io->d_points; a.d_n_points = io->d_n_points; a.d_inlier = io->d_pose_mask;
+        if (io->mode == MO_MODE_TRACK) {
+            if (!io->d_sel_idx || !io->d_sel_n) return mo_fail(c, MO_ERR_ARG, "MO_MODE_TRACK needs d_sel_idx and d_sel_n");
+            if ((rc = track_select_launch(c, io->d_kps, io->d_counts, qf, tf, io->d_match_idx, io->d_match_dist, io->d_match_pass,
+                                          io->cap, n_pairs, io->w, io->h, io->disp_frac, io->d_sel_idx, io->d_sel_dist, io->d_sel_n)))
+                return rc;
+            mo_stage_mark(c, "track_filters");
+            a.d_sel = io->d_sel_idx; a.d_sel_n = io->d_sel_n;
+        } else if (io->mode != MO_MODE_INIT) return mo_fail(c, MO_ERR_ARG, "mo_batch_io.mode must be MO_MODE_INIT or MO_MODE_TRACK");
         if ((rc = twoview_launch(c, a))) return rc;
         mo_stage_mark(c, "two_view");
     }

@@ -84,6 +84,9 @@ struct mo_ctx {
     size_t scratch_stride = 0;     // u64 entries per frame of overflow scratch
     FinalKp* d_fin = nullptr;      // [batch][fin_stride]
     int* d_fin_cnt = nullptr;      // [batch][MO_MAX_LEVELS]
+    uint32_t* d_tile_tab = nullptr; int n_tile_tab = 0;    // blur: tile -> level | tile column << 8 | tile row << 20 (built with the plan)
+    int tile_cum[MO_MAX_LEVELS + 1] = {};                  // tiles of levels < L (the table is level-major: a prefix blurs the first levels)
+    uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
     int* d_flags = nullptr;        // [4] error flags raised by kernels
     unsigned lds_attr_done = 0;    // bit per kernel whose max-dynamic-LDS attribute has been raised on this device
     // output staging for the host API
@@ -153,6 +156,8 @@ struct TwoViewArgs {
     uint64_t seed;
     // per pair: matches are read from the matcher outputs + keypoints, or from explicit point arrays
     const mo_keypoint* d_kps; const int32_t* d_counts; const int32_t* d_match_idx; const uint8_t* d_match_pass;
+    const int32_t* d_sel; const int32_t* d_sel_n;  // tracking mode: [pairs][cap][2] (queryIdx, trainIdx) in the caller's order + counts;
+                                                   // when set, these replace the ratio-test flags as the list of correspondences
     const float* d_p1; const float* d_p2; int m_fixed;  // explicit points (host API): [m][2]
     double* d_pose;   // [pairs][12]
     double* d_E;      // [pairs][9] or null
@@ -162,5 +167,9 @@ struct TwoViewArgs {
     int32_t* d_n_points; // [pairs]
 };
 int twoview_launch(mo_ctx* c, const TwoViewArgs& a);
+// track_kernels.hip
+int track_select_launch(mo_ctx* c, const mo_keypoint* d_kps, const int32_t* d_counts, const int32_t* d_qf, const int32_t* d_tf,
+                        const int32_t* d_midx, const int32_t* d_mdist, const uint8_t* d_mpass, int cap, int n_pairs, int w, int h,
+                        double disp_frac, int32_t* d_sel, int32_t* d_sel_dist, int32_t* d_sel_n);
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp);
 int triangulate_launch(mo_ctx* c, const double* P1, const double* P2, const float* d_p1, const float* d_p2, int n, float* d_X4);

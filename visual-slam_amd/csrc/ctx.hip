@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 
 #include <cstdlib>
 
@@ -82,8 +83,9 @@ static void free_plan_buffers(mo_ctx* c) {
         if (t.xofs) hipFree(t.xofs);
         t = ResizeTab();
     }
-    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt};
+    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab, c->d_strip_tab};
     for (void* b : bufs) if (b) hipFree(b);
+    c->d_tile_tab = c->d_strip_tab = nullptr; c->n_tile_tab = c->n_strip_tab = 0;
     c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_strip_cnt = nullptr; c->d_scratch = nullptr;
     c->d_fin = nullptr; c->d_fin_cnt = nullptr;
     c->batch_alloc = 0;

@@ -13,6 +13,8 @@
 //             + 256 rotated rBRIEF tests (4 per lane)
 // All arithmetic is integer or non-contracted float32 (compile with -ffp-contract=off) so results are
 // bit-identical to the CPU oracle.
+#include <cstring>
+
 #include "common.h"
 #include "select_replay.h"
 
@@ -60,17 +62,19 @@ int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, ui
 __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
                                                 uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
                                                 const int* __restrict__ xofs, const int* __restrict__ xc1,
-                                                const int* __restrict__ yofs, const int* __restrict__ yc1) {
+                                                const int* __restrict__ yofs, const int* __restrict__ yc1,
+                                                uint32_t inv_per, uint32_t inv_gx) {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_SRC_ROWS * RS_SRC_PITCH];
     __shared__ int s_xo[RS_TW], s_xc[RS_TW], s_yo[RS_TH], s_yc[RS_TH];
     const int tid = threadIdx.x;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if ((gridDim.z & 7) == 0) {  // XCD affinity (speed only): all tiles of a frame on one XCD (the level just written is in its L2)
-        const int per = gridDim.x * gridDim.y, lin = bx + gridDim.x * (by + gridDim.y * bz), n = lin >> 3;
-        bz = (lin & 7) + 8 * (n / per);
-        const int rem = n % per;
-        by = rem / (int)gridDim.x;
-        bx = rem - by * (int)gridDim.x;
+        // divisions by the host's reciprocals (0 encodes a divisor of 1); exact while dividend * divisor < 2^32
+        const uint32_t per = gridDim.x * gridDim.y, lin = bx + gridDim.x * (by + gridDim.y * bz), n = lin >> 3;
+        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n, rem = n - q * per;
+        bz = (int)((lin & 7) + 8 * q);
+        by = (int)(inv_gx ? __umulhi(rem, inv_gx) : rem);
+        bx = (int)(rem - (uint32_t)by * gridDim.x);
     }
     const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
     const uint8_t* s = src + (size_t)bz * src_fstride;
@@ -144,20 +148,15 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels)
         size_t sfs = L == 1 ? (size_t)P.w * P.h : (size_t)P.pyr_stride;
         const ResizeTab& t = c->rtab[L];
         dim3 grid((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, batch);
+        const uint32_t per = grid.x * grid.y, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u, inv_gx = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
-                           (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1);
+                           (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1, inv_per, inv_gx);
     }
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
 
 // ------------------------------------------------------------------ blur ----------------------------
-struct TileTab {
-    int nlevels;
-    int cum[MO_MAX_LEVELS + 1];  // cumulative tile counts
-    int tx[MO_MAX_LEVELS];       // tiles per row of each level
-};
-
 #define BT_W 64
 #define BT_H 26   // output rows per tile: 26 + 6 halo rows = 16 row pairs
 #define BT_PW 80  // LDS pixel-tile pitch: 4 (aligned lead-in) + 64 + 3 halo, rounded to a multiple of 16
@@ -173,21 +172,24 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
 // aligned dwords with v_alignbyte.  The u16 row sums of tile rows 2p and 2p+1 are stored interleaved in one dword per
 // column, so the column pass is four v_dot2_u32_u16 per output (tap pairs shifted by one row for odd output rows).
 // Interior tiles are staged with aligned dword loads; tiles touching the level border index with REFLECT_101.
-__global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* __restrict__ gray,
-                                              const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur) {
+__global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
+                                              const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                              uint8_t* __restrict__ blur) {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[BT_ROWS * BT_PW];
     __shared__ __attribute__((aligned(16))) uint32_t s_row[(BT_ROWS / 2) * BT_W];  // [row pair][column] = lo: even row, hi: odd
     int tile = blockIdx.x, frame = blockIdx.y;
     if ((gridDim.y & 7) == 0) {  // XCD affinity (speed only): all tiles of a frame on one XCD, so halo re-reads hit its L2
-        const int lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
-        frame = (lin & 7) + 8 * (n / (int)gridDim.x);
-        tile = n % (int)gridDim.x;
+        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
+        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / gridDim.x by the host's reciprocal (0: one per frame)
+        frame = (int)((lin & 7) + 8 * q);
+        tile = (int)(n - q * gridDim.x);
     }
-    int L = 0;
-    while (L + 1 < T.nlevels && tile >= T.cum[L + 1]) L++;
-    tile -= T.cum[L];
+    // one wave-uniform table read instead of a level search and two divisions per workgroup (the scalar prologue was as long
+    // as the vector body of these short-lived workgroups)
+    const uint32_t te = tile_tab[tile];
+    const int L = te & 0xFF;
     const LevelInfo lv = P.lv[L];
-    const int tx0 = (tile % T.tx[L]) * BT_W, ty0 = (tile / T.tx[L]) * BT_H;
+    const int tx0 = (int)((te >> 8) & 0xFFF) * BT_W, ty0 = (int)(te >> 20) * BT_H;
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int tid = threadIdx.x;
     // s_px column c holds level column tx0 - 4 + c  (c = 1 .. 70 are used).  Rows are reflected per tile row
@@ -270,15 +272,22 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, TileTab T, const uint8_t* 
 
 int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
     const Plan& P = c->plan;
-    TileTab T;
-    T.nlevels = nlevels;
-    T.cum[0] = 0;
-    for (int L = 0; L < nlevels; L++) {
-        T.tx[L] = (P.lv[L].w + BT_W - 1) / BT_W;
-        int ty = (P.lv[L].h + BT_H - 1) / BT_H;
-        T.cum[L + 1] = T.cum[L] + T.tx[L] * ty;
+    if (nlevels < 1 || nlevels > P.nlevels) return mo_fail(c, MO_ERR_ARG, "blur: level count outside the plan");
+    if (!c->d_tile_tab) {  // (re)built with the plan: free_plan_buffers drops it
+        std::vector<uint32_t> tab;
+        for (int L = 0; L < P.nlevels; L++) {
+            const int tx = (P.lv[L].w + BT_W - 1) / BT_W, ty = (P.lv[L].h + BT_H - 1) / BT_H;
+            c->tile_cum[L] = (int)tab.size();
+            for (int y = 0; y < ty; y++)
+                for (int x = 0; x < tx; x++) tab.push_back((uint32_t)L | ((uint32_t)x << 8) | ((uint32_t)y << 20));
+        }
+        c->tile_cum[P.nlevels] = (int)tab.size();
+        HIPCHK(c, hipMalloc((void**)&c->d_tile_tab, tab.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(c->d_tile_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->n_tile_tab = (int)tab.size();
     }
-    hipLaunchKernelGGL(k_blur, dim3(T.cum[nlevels], batch), dim3(256), 0, c->stream, P, T, d_gray, c->d_pyr, c->d_blur);
+    const uint32_t per = (uint32_t)c->tile_cum[nlevels], inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;  // first nlevels levels
+    hipLaunchKernelGGL(k_blur, dim3(per, batch), dim3(256), 0, c->stream, P, c->d_tile_tab, inv_per, d_gray, c->d_pyr, c->d_blur);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
@@ -347,19 +356,21 @@ __device__ __forceinline__ unsigned long long ballot_gt16(int a, int b) {
 #define FAST_STACK 384        // u16 entries per wavefront: two stacks of <= 191
 
 template <int TW>  // LDS tile pitch: a compile-time constant so the 16 circle reads use immediate offsets
-__global__ __launch_bounds__(256) void k_fast(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+__global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict__ strip_tab, uint32_t inv_per,
+                                              const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int strip = blockIdx.x, frame = blockIdx.y;
     if ((gridDim.y & 7) == 0) {  // XCD affinity (speed only): all strips of a frame on one XCD, so halo rows hit its L2
-        const int lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
-        frame = (lin & 7) + 8 * (n / (int)gridDim.x);
-        strip = n % (int)gridDim.x;
+        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
+        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / gridDim.x by the host's reciprocal (0: one per frame)
+        frame = (int)((lin & 7) + 8 * q);
+        strip = (int)(n - q * gridDim.x);
     }
-    int L = 0;
-    while (L + 1 < P.nlevels && strip >= P.lv[L + 1].strip_base) L++;
+    const uint32_t se = strip_tab[strip];  // one wave-uniform table read instead of a level search
+    const int L = se & 0xFF;
     const LevelInfo lv = P.lv[L];
-    strip -= lv.strip_base;
+    strip = (int)(se >> 8);
     if (strip >= lv.nstrips) return;
     const int R = lv.strip_rows;
     const int y0 = lv.by0 + strip * R;
@@ -586,8 +597,17 @@ template <int TW> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, in
         HIPCHK(c, hipFuncSetAttribute((const void*)k_fast<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         c->lds_attr_done |= bit;
     }
-    hipLaunchKernelGGL(k_fast<TW>, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, d_gray, c->d_pyr, c->d_cand,
-                       c->d_strip_cnt, (int)score_bytes);
+    if (!c->d_strip_tab) {  // (re)built with the plan: free_plan_buffers drops it
+        std::vector<uint32_t> tab((size_t)P.strips_per_frame, 0xFFFFFF00u);  // (no level has that many strips: the kernel returns)
+        for (int L = 0; L < P.nlevels; L++)
+            for (int st = 0; st < P.lv[L].nstrips; st++) tab[(size_t)P.lv[L].strip_base + st] = (uint32_t)L | ((uint32_t)st << 8);
+        HIPCHK(c, hipMalloc((void**)&c->d_strip_tab, tab.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(c->d_strip_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->n_strip_tab = (int)tab.size();
+    }
+    const uint32_t per = (uint32_t)P.strips_per_frame, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;
+    hipLaunchKernelGGL(k_fast<TW>, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, c->d_strip_tab, inv_per, d_gray,
+                       c->d_pyr, c->d_cand, c->d_strip_cnt, (int)score_bytes);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

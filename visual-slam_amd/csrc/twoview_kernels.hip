@@ -384,10 +384,24 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         if (tid == 0) w.m[pair] = m;
         return;
     }
-    // from matcher output: pair p = frame p (query) vs frame p+1 (train); survivors in query order
-    const int nq = min(a.d_counts[pair], a.cap);
     const mo_keypoint* k1 = a.d_kps + (size_t)pair * a.cap;
     const mo_keypoint* k2 = a.d_kps + (size_t)(pair + 1) * a.cap;
+    if (a.d_sel) {  // tracking mode: the filtered match list in the reference's order (track_kernels.hip)
+        const int m = min(a.d_sel_n[pair], a.cap);
+        const int32_t* sl = a.d_sel + (size_t)pair * a.cap * 2;
+        for (int o = tid; o < m; o += TV_BLOCK) {
+            const int i = sl[2 * o], j = sl[2 * o + 1];
+            float u1 = k1[i].x, v1 = k1[i].y, u2 = k2[j].x, v2 = k2[j].y;
+            px[4 * o] = u1; px[4 * o + 1] = v1; px[4 * o + 2] = u2; px[4 * o + 3] = v2;
+            xn[4 * o] = ((double)u1 - cx) / fx; xn[4 * o + 1] = ((double)v1 - cy) / fy;
+            xn[4 * o + 2] = ((double)u2 - cx) / fx; xn[4 * o + 3] = ((double)v2 - cy) / fy;
+            qidx[o] = i;
+        }
+        if (tid == 0) w.m[pair] = m;
+        return;
+    }
+    // from matcher output: pair p = frame p (query) vs frame p+1 (train); survivors in query order
+    const int nq = min(a.d_counts[pair], a.cap);
     const int32_t* midx = a.d_match_idx + (size_t)pair * a.cap * 2;
     const uint8_t* pass = a.d_match_pass + (size_t)pair * a.cap;
     for (int base = 0; base < nq; base += TV_BLOCK) {

@@ -5,8 +5,10 @@ The reference's Tracker/LocalMapper are not part of this repo; this small state 
 on the three classes (tracker.py:87,162,168-170,214,221,230,242-249) on a synthetic sequence (a camera translating past a
 two-depth scene), so the drop-in can be exercised end to end on an MI355X without cv2 or a video file:
     NOT_INITIALIZED: frame 0 -> set_first_frame, frame 1.. -> initialize (two-view map)
-    TRACKING: match against the previous frame, the two Python filters, essential matrix at threshold 1.0 + pose
-Usage: python visual-slam_amd/examples/run_frames.py [--frames 30] [--grid]
+    TRACKING: match against the previous frame, the two match filters, essential matrix at threshold 1.0 + pose - as one
+              fused device call (orbslam2.utils.track_from_last_frame, default) or with the filters as Python loops over
+              DMatch objects like the reference (--python-filters)
+Usage: python visual-slam_amd/examples/run_frames.py [--frames 30] [--grid] [--python-filters]
 """
 import argparse
 import os
@@ -49,6 +51,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--grid", action="store_true", help="use extract_features(distributed=True) like Tracker.process_frame")
+    ap.add_argument("--python-filters", action="store_true", help="tracking step through the per-method API (Python filter loops)")
     args = ap.parse_args()
     K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])    # configs/monocular.yaml:3
     extractor = ORBExtractor(n_features=2000, scale_factor=1.2, n_levels=8, ini_threshold=20, min_threshold=7)
@@ -69,6 +72,13 @@ def main():
                     state, n_map = "TRACKING", len(pts)
                     poses.append((R, t))
                     print("frame %d: initialised, %d map points, t = %s" % (i, n_map, np.round(t.ravel(), 3)))
+        elif not args.python_filters:
+            ok, T, inl = geom.track_from_last_frame(last[0], last[1], kps, desc, K, frame.shape, ratio_threshold=0.75,
+                                                    threshold_percent=0.02 * 2.5)
+            if ok:
+                poses.append((T[:3, :3], T[:3, 3:4]))
+                if i % 5 == 0:
+                    print("frame %d: %d pose inliers, t = %s" % (i, len(inl), np.round(T[:3, 3], 3)))
         else:
             m = matcher.match(last[1], desc)
             m = matcher.filter_matches_by_geometric_distance(last[0], kps, m, 0.02 * 2.5, frame.shape)

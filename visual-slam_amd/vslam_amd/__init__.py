@@ -44,7 +44,12 @@ class BatchIO(C.Structure):
                 ("seed", C.c_uint64),
                 ("d_kps", C.c_void_p), ("d_desc", C.c_void_p), ("d_counts", C.c_void_p), ("d_match_idx", C.c_void_p),
                 ("d_match_dist", C.c_void_p), ("d_match_pass", C.c_void_p), ("d_pose", C.c_void_p),
-                ("d_points", C.c_void_p), ("d_n_points", C.c_void_p)]
+                ("d_points", C.c_void_p), ("d_n_points", C.c_void_p),
+                ("mode", C.c_int32), ("disp_frac", C.c_double), ("d_sel_idx", C.c_void_p), ("d_sel_dist", C.c_void_p),
+                ("d_sel_n", C.c_void_p), ("d_pose_mask", C.c_void_p)]
+
+
+MODE_INIT, MODE_TRACK = 0, 1
 
 
 # every symbol include/vslam_amd.h declares: name -> (restype, argtypes)
@@ -62,6 +67,8 @@ SIGNATURES = {
     "mo_dbg_min_eigen": (_i, [_vp, _vp, _i, _i, _vp]),
     "mo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "mo_init_two_view": (_i, [_vp, _vp, _vp, _i, _vp, _d, _d, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mo_track_pair": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _d, _d, _vp, _d, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                           _vp]),
     "mo_triangulate_points": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mo_dev_frontend_batch": (_i, [_vp, _vp, _vp]),
     "mo_dev_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
@@ -111,7 +118,12 @@ def load_library():
     _preload_shared_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        try:
+            fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        except AttributeError:
+            if os.environ.get("VSLAM_AMD_LIB"):  # an older build under A/B timing (tools/ab.py) may predate a symbol
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     _lib = lib
@@ -272,6 +284,26 @@ class Context:
                                               _ptr(inl), _ptr(X), C.byref(ng)))
         return dict(R=R.reshape(3, 3), t=t.reshape(3, 1), E=E.reshape(3, 3), ransac_mask=ran[:m].astype(bool),
                     pose_mask=inl[:m].astype(bool), X=X[:m], n_good=ng.value)
+
+    def track_pair(self, kps1, desc1, kps2, desc2, width, height, K, ratio=0.75, disp_frac=0.02, thr_px=1.0, n_hyp=4096,
+                   seed=4096):
+        """One tracking step (reference tracker.py:214-254) on the device: match -> displacement filter -> 2 x median distance
+        filter -> essential matrix at thr_px -> pose.  kps*: structured KP_DTYPE arrays, desc*: (N, 32) uint8.
+        -> dict(sel (n, 2) int32 [queryIdx, trainIdx] in the reference's order, sel_dist, inlier (n,) bool, R, t, E, n_inliers)"""
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n1, n2 = len(k1), len(k2)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        R = np.zeros(9); t = np.zeros(3); E = np.zeros(9)
+        sel = np.zeros((max(n1, 1), 2), np.int32); sd = np.zeros(max(n1, 1), np.int32); inl = np.zeros(max(n1, 1), np.uint8)
+        ns, ni = C.c_int(0), C.c_int(0)
+        self._check(self.lib.mo_track_pair(self.h, _ptr(k1), n1, _ptr(d1), _ptr(k2), n2, _ptr(d2), int(width), int(height),
+                                           float(ratio if ratio is not None else 0.0), float(disp_frac), _ptr(Kc), float(thr_px),
+                                           int(n_hyp), C.c_uint64(int(seed)), _ptr(R), _ptr(t), _ptr(E), _ptr(sel), _ptr(sd),
+                                           C.byref(ns), _ptr(inl), C.byref(ni)))
+        n = ns.value
+        return dict(sel=sel[:n].copy(), sel_dist=sd[:n].copy(), inlier=inl[:n].astype(bool), R=R.reshape(3, 3), t=t.reshape(3, 1),
+                    E=E.reshape(3, 3), n_inliers=ni.value)
 
     def triangulate_points(self, P1, P2, p1, p2):
         P1 = np.ascontiguousarray(P1, np.float64).reshape(12)
