@@ -87,6 +87,15 @@ int mo_orb_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int w, int
 int mo_orb_grid_good_features(mo_ctx*, const uint8_t* img, int w, int h, int stride, int ch, int n_features, float* xy,
                               int* n_out);
 
+/* Replaces cv2.undistort(image, camera_matrix, distortion)   (utils.py:40-52, applied by run_video.py:145-149 when a distortion
+ * coefficient is non-zero): initUndistortRectifyMap (new camera matrix = K, 1/32-pixel fixed-point map) + remap(INTER_LINEAR,
+ * constant 0 border).  img / out: h x w x ch u8 (ch 1 or 3), rows at `stride` bytes (out is dense: w * ch); dist = k1, k2, p1, p2, k3.
+ * mo_dev_undistort: batch of dense frames already in HBM, enqueued on the context stream (run it ahead of
+ * mo_dev_orb_detect_compute / mo_dev_frontend_batch on the same stream). */
+int mo_undistort(mo_ctx*, const uint8_t* img, int w, int h, int stride, int ch, const double K[9], const double dist[5], uint8_t* out);
+int mo_dev_undistort(mo_ctx*, const uint8_t* d_src, int w, int h, int ch, int batch, const double K[9], const double dist[5],
+                     uint8_t* d_dst);
+
 /* ---- DescriptorMatcher ------------------------------------------------------------------- */
 /* Replaces BFMatcher(NORM_HAMMING).knnMatch(d1, d2, k=2) + the Lowe ratio loop (matcher.py:70,73-81).
  * q [batch][nq][32], t [batch][nt][32]; ratio NULL = no ratio test (ratio_test=False).
@@ -107,6 +116,22 @@ int mo_init_two_view(mo_ctx*, const float* p1, const float* p2, int m, const dou
                      double prob, int n_hyp, uint64_t seed, double R[9], double t[3], double E[9],
                      uint8_t* ransac_inlier /* [m] findEssentialMat mask, may be NULL */, uint8_t* inlier, float* X,
                      int* n_good);
+
+/* Replaces cv2.recoverPose(E, p1, p2, K, mask)   (utils.py:129-134) for ANY essential matrix the caller holds: decomposition
+ * (U W V^T, U W^T V^T, +-u3), cheirality vote over the four candidates on the points selected by mask_in (NULL = all; depth in
+ * (0, 50) in both cameras, as cv2), winner's R, t, its mask, and the DLT points of the surviving correspondences.
+ * p1, p2 [m][2] pixels, K row-major; mask_out [m]; X [m][3] (may be NULL; NaN where mask_out is 0); n_good. */
+int mo_recover_pose(mo_ctx*, const double E[9], const float* p1, const float* p2, int m, const double K[9],
+                    const uint8_t* mask_in, double R[9], double t[3], uint8_t* mask_out, float* X, int* n_good);
+
+/* Replaces cv2.findFundamentalMat(points1, points2, cv2.FM_RANSAC, thr_px, prob)   (matcher.py:191 filter_matches_by_fundamental,
+ * local_mapper.py:136 keyframe map growth).  Same machinery as mo_init_two_view with the fundamental-matrix model: n_hyp
+ * 8-point hypotheses on Hartley-normalised pixel coordinates, rank-2 projection, MSAC ranking on the Sampson distance in pixels,
+ * least-squares refit on the consensus set.  (cv2's FM_RANSAC draws 7-point samples; like the 8-point essential RANSAC this
+ * is the parallel-hypothesis formulation north_star prescribes - parity is on the inlier set and the epipolar geometry.)
+ * p1, p2 [m][2] pixels; F [9] row-major scaled to F[8] = 1 (NaN when m < 8 or no model is found); mask [m]; n_inliers. */
+int mo_find_fundamental(mo_ctx*, const float* p1, const float* p2, int m, double thr_px, double prob, int n_hyp, uint64_t seed,
+                        double F[9], uint8_t* mask, int* n_inliers);
 
 /* One tracking step of Tracker._track_from_last_frame (tracker.py:214-254) for a single frame pair, host in / host out:
  * matcher.match(prev, cur) -> displacement filter (matcher.py:109-142, frac = 0.02 of (w + h) / 2) -> 2 x median distance

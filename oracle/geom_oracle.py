@@ -232,3 +232,94 @@ def track_pair(xy1, xy2, idx, dist, keep, K, width, height, frac=0.02, thr_px=1.
     r = init_two_view(np.asarray(xy1, np.float32)[q], np.asarray(xy2, np.float32)[t], K, thr_px, n_hyp, seed, pair)
     out.update(R=r["R"], t=r["t"], E=r["E"], pose_mask=r["pose_mask"], ransac_mask=r["ransac_mask"], n_good=r["n_good"], X=r["X"])
     return out
+
+
+# ---- fundamental matrix (reference matcher.py:191, local_mapper.py:136: cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr, prob)) ---
+def find_fundamental_ransac8(p1, p2, thr_px=3.0, n_hyp=4096, seed=4096, pair=0, chunk=512):
+    """8-point fundamental-matrix RANSAC over a fixed number of hypotheses, same structure and sampling stream as
+    find_essential_ransac8 (cv2's FM_RANSAC is a sequential 7-point RANSAC: PARITY UNPINNED against cv2, pinned against the HIP
+    path and synthetic ground truth).  Pixel coordinates are Hartley-normalised x_n = s (x - centroid) with ONE scale for both
+    images (mean distance from the centroids -> sqrt 2), so Sampson distances scale by s^2 and the threshold is thr_px * s.
+    -> (F 3x3 scaled to F[2,2] = 1, or None; mask (M,) bool)"""
+    p1 = np.asarray(p1, np.float32).astype(np.float64); p2 = np.asarray(p2, np.float32).astype(np.float64)
+    m = len(p1)
+    if m < 8:
+        return None, np.zeros(m, bool)
+    c1, c2 = p1.mean(axis=0), p2.mean(axis=0)
+    mean = (np.linalg.norm(p1 - c1, axis=1).sum() + np.linalg.norm(p2 - c2, axis=1).sum()) / (2.0 * m)
+    s = np.sqrt(2.0) / mean if mean > 1e-12 else 1.0
+    x1, x2 = s * (p1 - c1), s * (p2 - c2)
+    thr2 = (thr_px * s) ** 2
+
+    def rank2(F):
+        U, sv, Vt = np.linalg.svd(F)
+        sv = sv.copy(); sv[..., 2] = 0.0
+        return (U * sv[..., None, :]) @ Vt
+
+    samples = np.array([sample8(seed, h, m, pair) for h in range(n_hyp)])
+    A = _design(x1[samples.ravel()], x2[samples.ravel()]).reshape(n_hyp, 8, 9)
+    _, _, Vt = np.linalg.svd(A)
+    Fs = rank2(Vt[:, -1, :].reshape(n_hyp, 3, 3))
+    cost = np.full(n_hyp, np.inf, np.float32)
+    for a in range(0, n_hyp, chunk):
+        d = sampson(Fs[a:a + chunk], x1, x2)
+        cost[a:a + chunk] = np.minimum(d, thr2).sum(axis=1).astype(np.float32)
+    F = Fs[int(np.argmin(cost))]
+    n0 = int((sampson(F, x1, x2) <= thr2).sum())
+    if n0 < 8:
+        return None, np.zeros(m, bool)
+    lo2 = thr2 / 4096.0
+    d = sampson(F, x1, x2)
+    sel = d <= thr2
+    tau2 = min(max(9.0 * float(d[sel].sum()) / int(sel.sum()), lo2), thr2)
+    c_prev, tau2_prev = -1, -1.0
+    for _ in range(5):  # same adaptive-threshold refits as the essential model
+        d = sampson(F, x1, x2)
+        sel = d <= tau2
+        c = int(sel.sum())
+        if c < 8 or 2 * c < n0:
+            break
+        if c == c_prev and tau2 == tau2_prev:
+            break
+        c_prev, tau2_prev = c, tau2
+        _, _, Vt = np.linalg.svd(_design(x1[sel], x2[sel]), full_matrices=False)
+        F = rank2(Vt[-1].reshape(3, 3))
+        tau2 = min(max(9.0 * float(d[sel].sum()) / c, lo2), thr2)
+    mask = sampson(F, x1, x2) <= thr2
+    T1 = np.array([[s, 0, -s * c1[0]], [0, s, -s * c1[1]], [0, 0, 1.0]])
+    T2 = np.array([[s, 0, -s * c2[0]], [0, s, -s * c2[1]], [0, 0, 1.0]])
+    Fp = T2.T @ F @ T1
+    nn = np.linalg.norm(Fp)
+    Fp = Fp / Fp[2, 2] if abs(Fp[2, 2]) > 1e-12 * nn else Fp / nn
+    return Fp, mask
+
+
+# ---- undistort (reference src/orbslam2/utils.py:40-52: cv2.undistort(image, camera_matrix, distortion)) ------------------------
+def undistort(image, K, dist):
+    """cv2.undistort for uint8 images restated from OpenCV's published pipeline (PARITY UNPINNED against cv2: the reference holds
+    no undistorted fixture): initUndistortRectifyMap(K, dist, I, K, CV_16SC2) in double, map quantised to 1/32 px with
+    round-half-even, remap(INTER_LINEAR, BORDER_CONSTANT 0) with the exact fixed-point bilinear table of 32 steps:
+    out = (sum (32 - a | a)(32 - b | b) p + 512) >> 10."""
+    img = np.asarray(image, np.uint8)
+    h, w = img.shape[:2]
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    d = np.zeros(5); dd = np.asarray(dist, np.float64).ravel(); d[:min(5, len(dd))] = dd[:5]
+    k1, k2, p1, p2, k3 = d
+    j, i = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    x = (j - K[0, 2]) / K[0, 0]; y = (i - K[1, 2]) / K[1, 1]
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2; xy2 = 2 * x * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * xy2 + p2 * (r2 + 2 * x2); yd = y * kr + p1 * (r2 + 2 * y2) + p2 * xy2
+    u = K[0, 0] * xd + K[0, 2]; v = K[1, 1] * yd + K[1, 2]
+    iu = np.rint(np.clip(u * 32.0, -1e8, 1e8)).astype(np.int64); iv = np.rint(np.clip(v * 32.0, -1e8, 1e8)).astype(np.int64)
+    sx, sy, a, b = iu >> 5, iv >> 5, iu & 31, iv & 31
+    src = img.reshape(h, w, -1).astype(np.int64)
+
+    def tap(yy, xx):
+        ok = (xx >= 0) & (xx < w) & (yy >= 0) & (yy < h)
+        return np.where(ok[..., None], src[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)], 0)
+
+    acc = ((32 - a) * (32 - b))[..., None] * tap(sy, sx) + (a * (32 - b))[..., None] * tap(sy, sx + 1) + \
+          ((32 - a) * b)[..., None] * tap(sy + 1, sx) + (a * b)[..., None] * tap(sy + 1, sx + 1)
+    return ((acc + 512) >> 10).astype(np.uint8).reshape(img.shape)

@@ -193,6 +193,37 @@ extern "C" int mo_orb_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* 
     return MO_OK;
 }
 
+extern "C" int mo_dev_undistort(mo_ctx* c, const uint8_t* d_src, int w, int h, int ch, int batch, const double K[9],
+                                const double dist[5], uint8_t* d_dst) {
+    if (!c) return MO_ERR_ARG;
+    if (!d_src || !d_dst || !K || !dist || d_src == d_dst) return mo_fail(c, MO_ERR_ARG, "NULL argument (or in-place)");
+    if (w < 1 || h < 1 || batch < 1 || (ch != 1 && ch != 3)) return mo_fail(c, MO_ERR_ARG, "bad size / channel count");
+    if (!(K[0] != 0.0) || !(K[4] != 0.0)) return mo_fail(c, MO_ERR_ARG, "focal length is zero");
+    HIPCHK(c, hipSetDevice(c->device));
+    return undistort_launch(c, d_src, d_dst, w, h, ch, batch, K, dist);
+}
+
+extern "C" int mo_undistort(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int ch, const double K[9], const double dist[5],
+                            uint8_t* out) {
+    if (!c) return MO_ERR_ARG;
+    if (!img || !out || !K || !dist) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    if (w < 1 || h < 1 || (ch != 1 && ch != 3) || stride < w * ch) return mo_fail(c, MO_ERR_ARG, "bad size / stride / channel count");
+    if (!(K[0] != 0.0) || !(K[4] != 0.0)) return mo_fail(c, MO_ERR_ARG, "focal length is zero");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t row = (size_t)w * ch, frame = row * h;
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, 2 * frame + 256);
+    if (rc) return rc;
+    uint8_t* d_src = (uint8_t*)c->d_tmp;
+    uint8_t* d_dst = d_src + ((frame + 255) & ~(size_t)255);
+    HIPCHK(c, hipMemcpy2DAsync(d_src, row, img, (size_t)stride, row, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    mo_stage_begin(c);
+    if ((rc = undistort_launch(c, d_src, d_dst, w, h, ch, 1, K, dist))) return rc;
+    mo_stage_mark(c, "undistort");
+    HIPCHK(c, hipMemcpyAsync(out, d_dst, frame, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MO_OK;
+}
+
 static int gftt_run(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int ch, int n_features, float* xy, int* n_out,
                     float* eig_out) {
     if (w < 64 || h < 64 || w > c->max_w || h > c->max_h) return mo_fail(c, MO_ERR_ARG, "image size outside the context limits");
@@ -334,6 +365,91 @@ extern "C" int mo_init_two_view(mo_ctx* c, const float* p1, const float* p2, int
     for (int i = 0; i < 9; i++) R[i] = pose[i];
     for (int i = 0; i < 3; i++) t[i] = pose[9 + i];
     *n_good = ng;
+    return MO_OK;
+}
+
+extern "C" int mo_recover_pose(mo_ctx* c, const double E[9], const float* p1, const float* p2, int m, const double K[9],
+                               const uint8_t* mask_in, double R[9], double t[3], uint8_t* mask_out, float* X, int* n_good) {
+    if (!c) return MO_ERR_ARG;
+    if (!E || !K || !R || !t || !n_good || m < 0 || (m > 0 && (!p1 || !p2 || !mask_out))) return mo_fail(c, MO_ERR_ARG, "NULL / negative argument");
+    if (m > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "m must be 0..4096");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_good = 0;
+    for (int i = 0; i < 9; i++) R[i] = NAN;
+    for (int i = 0; i < 3; i++) t[i] = NAN;
+    if (m == 0) return MO_OK;
+    const size_t pb = (size_t)m * 2 * sizeof(float);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_p1 = take(pb), o_p2 = take(pb), o_E = take(9 * sizeof(double)), o_min = take(m), o_pose = take(12 * sizeof(double)),
+                 o_X = take((size_t)m * 3 * sizeof(float)), o_inl = take(m), o_n = take(sizeof(int32_t));
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    HIPCHK(c, hipMemcpyAsync(b + o_p1, p1, pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_p2, p2, pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_E, E, 9 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    if (mask_in) HIPCHK(c, hipMemcpyAsync(b + o_min, mask_in, (size_t)m, hipMemcpyHostToDevice, c->stream));
+    TwoViewArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_pairs = 1; a.cap = m; a.n_hyp = 0;
+    for (int i = 0; i < 9; i++) a.K[i] = K[i];
+    a.thr_px = 1.0;
+    a.d_p1 = (const float*)(b + o_p1); a.d_p2 = (const float*)(b + o_p2); a.m_fixed = m;
+    a.d_E_in = (const double*)(b + o_E); a.d_mask_in = mask_in ? b + o_min : nullptr;
+    a.d_pose = (double*)(b + o_pose); a.d_points = (float*)(b + o_X); a.d_inlier = b + o_inl; a.d_n_points = (int32_t*)(b + o_n);
+    mo_stage_begin(c);
+    if ((rc = twoview_launch(c, a))) return rc;
+    mo_stage_mark(c, "recover_pose");
+    double pose[12];
+    int32_t ng = 0;
+    HIPCHK(c, hipMemcpyAsync(pose, b + o_pose, sizeof(pose), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mask_out, b + o_inl, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (X) HIPCHK(c, hipMemcpyAsync(X, b + o_X, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ng, b + o_n, sizeof(ng), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 9; i++) R[i] = pose[i];
+    for (int i = 0; i < 3; i++) t[i] = pose[9 + i];
+    *n_good = ng;
+    return MO_OK;
+}
+
+extern "C" int mo_find_fundamental(mo_ctx* c, const float* p1, const float* p2, int m, double thr_px, double prob, int n_hyp,
+                                   uint64_t seed, double F[9], uint8_t* mask, int* n_inliers) {
+    (void)prob;
+    if (!c) return MO_ERR_ARG;
+    if (!F || !n_inliers || m < 0 || (m > 0 && (!p1 || !p2 || !mask))) return mo_fail(c, MO_ERR_ARG, "NULL / negative argument");
+    if (m > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "m must be 0..4096");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_inliers = 0;
+    for (int i = 0; i < 9; i++) F[i] = NAN;
+    if (m < 8) { if (m > 0) std::memset(mask, 0, (size_t)m); return MO_OK; }
+    const size_t pb = (size_t)m * 2 * sizeof(float);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_p1 = take(pb), o_p2 = take(pb), o_F = take(9 * sizeof(double)), o_X = take((size_t)m * 3 * sizeof(float)),
+                 o_ran = take(m), o_n = take(sizeof(int32_t));
+    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off);
+    if (rc) return rc;
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    HIPCHK(c, hipMemcpyAsync(b + o_p1, p1, pb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_p2, p2, pb, hipMemcpyHostToDevice, c->stream));
+    TwoViewArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.n_pairs = 1; a.cap = m; a.n_hyp = n_hyp; a.model = 1;
+    a.K[0] = a.K[4] = a.K[8] = 1.0;
+    a.thr_px = thr_px; a.seed = seed;
+    a.d_p1 = (const float*)(b + o_p1); a.d_p2 = (const float*)(b + o_p2); a.m_fixed = m;
+    a.d_E = (double*)(b + o_F); a.d_points = (float*)(b + o_X); a.d_ransac = b + o_ran; a.d_n_points = (int32_t*)(b + o_n);
+    mo_stage_begin(c);
+    if ((rc = twoview_launch(c, a))) return rc;
+    mo_stage_mark(c, "find_fundamental");
+    int32_t ng = 0;
+    HIPCHK(c, hipMemcpyAsync(F, b + o_F, 9 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(mask, b + o_ran, (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&ng, b + o_n, sizeof(ng), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n_inliers = ng;
     return MO_OK;
 }
 

@@ -152,6 +152,8 @@ int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, 
 // twoview_kernels.hip
 struct TwoViewArgs {
     int n_pairs, cap, n_hyp;
+    int model;  // 0: essential matrix (K-normalised coordinates, thr_px / focal) + pose + triangulation;
+                // 1: fundamental matrix (pixel coordinates, Hartley-normalised with one common scale): F in d_E, mask in d_ransac
     double K[9], thr_px;
     uint64_t seed;
     // per pair: matches are read from the matcher outputs + keypoints, or from explicit point arrays
@@ -159,6 +161,8 @@ struct TwoViewArgs {
     const int32_t* d_sel; const int32_t* d_sel_n;  // tracking mode: [pairs][cap][2] (queryIdx, trainIdx) in the caller's order + counts;
                                                    // when set, these replace the ratio-test flags as the list of correspondences
     const float* d_p1; const float* d_p2; int m_fixed;  // explicit points (host API): [m][2]
+    const double* d_E_in; const uint8_t* d_mask_in;     // recoverPose on a GIVEN essential matrix ([pairs][9]) and consensus mask
+                                                        // ([pairs][cap] by query index, may be null = all): no RANSAC, no refit
     double* d_pose;   // [pairs][12]
     double* d_E;      // [pairs][9] or null
     float* d_points;  // [pairs][cap][3]
@@ -167,6 +171,9 @@ struct TwoViewArgs {
     int32_t* d_n_points; // [pairs]
 };
 int twoview_launch(mo_ctx* c, const TwoViewArgs& a);
+// undistort_kernels.hip
+int undistort_launch(mo_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int ch, int batch, const double K[9],
+                     const double dist[5]);
 // track_kernels.hip
 int track_select_launch(mo_ctx* c, const mo_keypoint* d_kps, const int32_t* d_counts, const int32_t* d_qf, const int32_t* d_tf,
                         const int32_t* d_midx, const int32_t* d_mdist, const uint8_t* d_mpass, int cap, int n_pairs, int w, int h,

@@ -38,6 +38,8 @@ struct TvWork {
     int* n_alive;      // [pairs]
     int* n_tasks;      // [1] number of 64-survivor tasks of the whole launch
     int2* task;        // [pairs * ceil(n_hyp / 64)] (pair, first survivor) of each task, dense from index 0
+    double* norm;      // [pairs][8] fundamental-matrix model: common scale s, centroid 1 (x, y), centroid 2 (x, y) of the
+                       // Hartley normalisation x_n = s (x - c); Sampson distances scale by s^2, so thr_n = thr_px * s
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
@@ -45,7 +47,7 @@ size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
     return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 +
            p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + p * (size_t)n_hyp * sizeof(double) +
            p * sizeof(unsigned) + p * (size_t)n_hyp * sizeof(unsigned short) + p * sizeof(int) + 16 +
-           p * (size_t)((n_hyp + 63) / 64) * sizeof(int2) + 1024;
+           p * (size_t)((n_hyp + 63) / 64) * sizeof(int2) + p * 8 * sizeof(double) + 1024;
 }
 
 static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
@@ -56,6 +58,7 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     w.hypE = (double*)b; b += p * (size_t)n_hyp * 9 * sizeof(double);
     w.best = (unsigned long long*)b; b += p * sizeof(unsigned long long);
     w.part = (double*)b; b += p * (size_t)n_hyp * sizeof(double);
+    w.norm = (double*)b; b += p * 8 * sizeof(double);
     w.px = (float*)b; b += p * cap * 4 * sizeof(float);
     w.qidx = (int*)b; b += p * cap * sizeof(int);
     w.m = (int*)b; b += p * sizeof(int);
@@ -360,7 +363,65 @@ __device__ bool eight_point(const double* pts /* [8][4] */, double* E) {
     return ok;
 }
 
+// Sampson threshold in the coordinates the hypotheses live in
+__device__ __forceinline__ double tv_thr(const TwoViewArgs& a, const TvWork& w, int pair) {
+    return a.model ? a.thr_px * w.norm[(size_t)pair * 8] : a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+}
+
+// nearest rank-2 matrix (smallest singular value -> 0): the fundamental-matrix constraint
+__device__ bool project_rank2(double* F) {
+    double U[9], V[9], s[3];
+    if (!svd3_rank2(F, U, V, s)) return false;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) F[i * 3 + j] = s[0] * U[i * 3] * V[j * 3] + s[1] * U[i * 3 + 1] * V[j * 3 + 1];
+    return true;
+}
+
 // ---------------------------------------------------------------- prep ----------------------------
+// Fundamental-matrix model: replace the K-normalised coordinates by Hartley-normalised pixel coordinates x_n = s (x - c) with
+// the centroid of each image and ONE scale for both (mean distance from the centroids -> sqrt 2), so that a Sampson distance
+// in these coordinates is s^2 times the distance in pixels and the scoring kernels need no per-image weights.
+// Called by all threads of the prep block after px[0 .. m) has been written.
+__device__ void tv_hartley(const TwoViewArgs& a, const TvWork& w, int pair, int m) {
+    __shared__ double s_h[TV_BLOCK / 64][5];
+    __shared__ double s_nrm[5];
+    const int tid = threadIdx.x;
+    const float* px = w.px + (size_t)pair * a.cap * 4;
+    double* xn = w.xn + (size_t)pair * a.cap * 4;
+    __syncthreads();  // px of this block is complete
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = tid; i < m; i += TV_BLOCK)
+        for (int k = 0; k < 4; k++) acc[k] += (double)px[4 * i + k];
+    for (int k = 0; k < 4; k++) {
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        if ((tid & 63) == 0) s_h[tid >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < 4) s_nrm[1 + tid] = (s_h[0][tid] + s_h[1][tid] + s_h[2][tid] + s_h[3][tid]) / (double)max(m, 1);
+    __syncthreads();
+    const double c1x = s_nrm[1], c1y = s_nrm[2], c2x = s_nrm[3], c2y = s_nrm[4];
+    double dsum = 0;
+    for (int i = tid; i < m; i += TV_BLOCK) {
+        const double a1 = (double)px[4 * i] - c1x, b1 = (double)px[4 * i + 1] - c1y, a2 = (double)px[4 * i + 2] - c2x, b2 = (double)px[4 * i + 3] - c2y;
+        dsum += sqrt(a1 * a1 + b1 * b1) + sqrt(a2 * a2 + b2 * b2);
+    }
+    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o, 64);
+    if ((tid & 63) == 0) s_h[tid >> 6][4] = dsum;
+    __syncthreads();
+    if (tid == 0) {
+        const double mean = (s_h[0][4] + s_h[1][4] + s_h[2][4] + s_h[3][4]) / (2.0 * (double)max(m, 1));
+        s_nrm[0] = mean > 1e-12 ? 1.4142135623730951 / mean : 1.0;
+        double* o = w.norm + (size_t)pair * 8;
+        o[0] = s_nrm[0]; o[1] = c1x; o[2] = c1y; o[3] = c2x; o[4] = c2y;
+    }
+    __syncthreads();
+    const double sc = s_nrm[0];
+    for (int i = tid; i < m; i += TV_BLOCK) {
+        xn[4 * i] = sc * ((double)px[4 * i] - c1x); xn[4 * i + 1] = sc * ((double)px[4 * i + 1] - c1y);
+        xn[4 * i + 2] = sc * ((double)px[4 * i + 2] - c2x); xn[4 * i + 3] = sc * ((double)px[4 * i + 3] - c2y);
+    }
+}
+
 __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     const int pair = blockIdx.x, tid = threadIdx.x;
     __shared__ int s_w[TV_BLOCK / 64];
@@ -382,6 +443,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
             qidx[i] = i;
         }
         if (tid == 0) w.m[pair] = m;
+        if (a.model) tv_hartley(a, w, pair, m);
         return;
     }
     const mo_keypoint* k1 = a.d_kps + (size_t)pair * a.cap;
@@ -398,6 +460,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
             qidx[o] = i;
         }
         if (tid == 0) w.m[pair] = m;
+        if (a.model) tv_hartley(a, w, pair, m);
         return;
     }
     // from matcher output: pair p = frame p (query) vs frame p+1 (train); survivors in query order
@@ -428,6 +491,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         __syncthreads();
     }
     if (tid == 0) w.m[pair] = s_base;
+    if (a.model) tv_hartley(a, w, pair, s_base);
 }
 
 // ---------------------------------------------------------------- hypotheses ----------------------
@@ -442,7 +506,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     const int m = w.m[pair];
     if (m < 8) return;
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
-    const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+    const double thr = tv_thr(a, w, pair);
     const double thr2 = thr * thr;
     double E[9];
     bool valid = h < a.n_hyp;
@@ -452,7 +516,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
         double pts[32];
         for (int k = 0; k < 8; k++)
             for (int j = 0; j < 4; j++) pts[k * 4 + j] = xn[(size_t)idx[k] * 4 + j];
-        valid = eight_point(pts, E) && project_essential(E);
+        valid = eight_point(pts, E) && (a.model ? project_rank2(E) : project_essential(E));
     }
     if (!valid) for (int j = 0; j < 9; j++) E[j] = 0.0;
     if (h < a.n_hyp) {
@@ -565,7 +629,7 @@ __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
     const int pair = tk.x, t0 = tk.y;
     const int total = w.n_alive[pair];
     const int m = w.m[pair];
-    const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+    const double thr = tv_thr(a, w, pair);
     const double thr2 = thr * thr;
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
     typedef const __attribute__((address_space(4))) double* cdp;
@@ -652,8 +716,9 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
         if (inl_out) inl_out[i] = 0;
         if (ran_out) ran_out[i] = 0;
     }
-    const unsigned long long best = w.best[pair];
-    if (m < 8 || best == ~0ull) {
+    const bool given = a.d_E_in != nullptr;  // recoverPose mode: E and the consensus mask come from the caller
+    const unsigned long long best = given ? 0ull : w.best[pair];
+    if (given ? m < 1 : (m < 8 || best == ~0ull)) {
         if (tid == 0) {
             a.d_n_points[pair] = 0;
             if (pose) for (int j = 0; j < 12; j++) pose[j] = __longlong_as_double(0x7FF8000000000000ll);
@@ -665,9 +730,9 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
     const float* px = w.px + (size_t)pair * a.cap * 4;
     const int* qidx = w.qidx + (size_t)pair * a.cap;
-    const double thr = a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
+    const double thr = tv_thr(a, w, pair);
     const double thr2 = thr * thr;
-    if (tid < 9) s_E[tid] = w.hypE[((size_t)pair * a.n_hyp + hbest) * 9 + tid];
+    if (tid < 9) s_E[tid] = given ? a.d_E_in[(size_t)pair * 9 + tid] : w.hypE[((size_t)pair * a.n_hyp + hbest) * 9 + tid];
     __syncthreads();
 
     // ---- local optimisation: least-squares 8-point refits (9x9 normal matrix, 45 unique sums, Jacobi) on an
@@ -678,6 +743,7 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     __shared__ double s_R[TVF_BLOCK * 9];          // constraint rows of one pass
     __shared__ double s_tile[TVF_BLOCK / 64][256];  // per-wavefront partial Gram tiles
     __shared__ int s_stop;
+    if (!given) {  // block-uniform
     const double lo2 = thr2 / 4096.0;
     int n0;
     double tau2;
@@ -765,7 +831,7 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
             en = 1.0 / sqrt(en);
             for (int i = 0; i < 9; i++) E[i] *= en;
             smallest_eigvec<9>(Nn, E, 16);
-            bool ok = project_essential(E);
+            bool ok = a.model ? project_rank2(E) : project_essential(E);
             if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
             s_stop = ok ? 0 : 1;
         }
@@ -773,7 +839,36 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
         if (s_stop) break;
         tau2 = fmin(fmax(9.0 * sds / c, lo2), thr2);
     }
+    }
     __syncthreads();
+    if (a.model) {  // fundamental matrix: mask = Sampson distance within thr (pixels), F back in pixel coordinates; no pose
+        double Fn[9];
+        for (int j = 0; j < 9; j++) Fn[j] = s_E[j];
+        int cnt = 0;
+        for (int i = tid; i < m; i += TVF_BLOCK) {
+            const bool in = sampson(Fn, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]) <= thr2;
+            if (in) { cnt++; if (ran_out) ran_out[qidx[i]] = 1; if (inl_out) inl_out[qidx[i]] = 1; }
+        }
+        const int total = block_sum_i(cnt, s_redi);
+        if (tid == 0) {
+            a.d_n_points[pair] = total;
+            if (pose) for (int j = 0; j < 12; j++) pose[j] = __longlong_as_double(0x7FF8000000000000ll);
+            if (a.d_E) {  // F = T2^T Fn T1 with T = [s 0 -s cx; 0 s -s cy; 0 0 1], scaled to F33 = 1 like cv2 (unit norm if F33 ~ 0)
+                const double* nm = w.norm + (size_t)pair * 8;
+                const double sc = nm[0];
+                const double T1[9] = {sc, 0, -sc * nm[1], 0, sc, -sc * nm[2], 0, 0, 1};
+                const double T2[9] = {sc, 0, -sc * nm[3], 0, sc, -sc * nm[4], 0, 0, 1};
+                double A[9], F[9], nn = 0;
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) { double v = 0; for (int q = 0; q < 3; q++) v += Fn[i * 3 + q] * T1[q * 3 + j]; A[i * 3 + j] = v; }
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) { double v = 0; for (int q = 0; q < 3; q++) v += T2[q * 3 + i] * A[q * 3 + j]; F[i * 3 + j] = v; nn += v * v; }
+                const double sF = fabs(F[8]) > 1e-12 * sqrt(nn) ? 1.0 / F[8] : 1.0 / sqrt(nn);
+                for (int j = 0; j < 9; j++) a.d_E[(size_t)pair * 9 + j] = F[j] * sF;
+            }
+        }
+        return;
+    }
     if (tid == 0) {
         // decompose: R1 = U W V^T, R2 = U W^T V^T, t = u3
         double U[9], Vm[9], sg[3], Ef[9];
@@ -821,7 +916,8 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     for (int i = tid; i < m; i += TVF_BLOCK, slot++) {
         double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
         unsigned bits = 0;
-        if (sampson(E, x1, y1, x2, y2) <= thr2) {
+        const bool consider = given ? (!a.d_mask_in || a.d_mask_in[(size_t)pair * a.cap + qidx[i]] != 0) : sampson(E, x1, y1, x2, y2) <= thr2;
+        if (consider) {
             for (int cnd = 0; cnd < 4; cnd++) {
                 double Pc[12], X[4];
                 for (int j = 0; j < 12; j++) Pc[j] = s_P[cnd][j];
@@ -903,12 +999,17 @@ int triangulate_launch(mo_ctx* c, const double* P1, const double* P2, const floa
 int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
     if (a.n_pairs <= 0) return MO_OK;
     if (a.cap > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "two-view stage supports at most 4096 correspondences per pair");
-    if (a.n_hyp < 1 || a.n_hyp > (1 << 20)) return mo_fail(c, MO_ERR_ARG, "n_hyp out of range");
+    if (!a.d_E_in && (a.n_hyp < 1 || a.n_hyp > (1 << 20))) return mo_fail(c, MO_ERR_ARG, "n_hyp out of range");
     size_t need = twoview_workspace_bytes(a.n_pairs, a.cap, a.n_hyp);
     int rc = mo_reserve(c, c->d_tv, c->tv_bytes, need);
     if (rc) return rc;
     TvWork w = carve(c->d_tv, a.n_pairs, a.cap, a.n_hyp);
     hipLaunchKernelGGL(k_tv_prep, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+    if (a.d_E_in) {  // recoverPose on a given E: decomposition + cheirality vote + triangulation only
+        hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
+        HIPCHK(c, hipGetLastError());
+        return MO_OK;
+    }
     const int staged = a.n_hyp >= 512 && a.n_hyp <= 65536;  // the survivor list is u16
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged);
     if (staged) {

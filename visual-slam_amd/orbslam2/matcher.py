@@ -5,6 +5,7 @@
   match      matcher.py:44-83   None / empty -> []; cast to uint8; knnMatch(k=2) + Lowe ratio in query order
   filter_matches_by_geometric_distance  matcher.py:109-142   host list logic
   filter_matches_by_distance            matcher.py:144-169   host list logic
+  filter_matches_by_fundamental         matcher.py:171-200   HIP F-matrix RANSAC (mo_find_fundamental)
 """
 import math
 
@@ -76,7 +77,16 @@ class DescriptorMatcher:
         return [m for m in ordered if m.distance < distance_threshold]
 
     def filter_matches_by_fundamental(self, keypoints1, keypoints2, matches, threshold=3.0):
-        raise NotImplementedError("F-matrix RANSAC filter is not on the hot path (no caller, SURVEY.md 2.1)")
+        """matcher.py:171-200: cv2.findFundamentalMat(points1, points2, FM_RANSAC, threshold, 0.99) -> (inlier matches, bool mask);
+        fewer than 8 matches are returned unfiltered with an all-true mask, like the reference."""
+        if len(matches) < 8:
+            return matches, np.ones(len(matches), dtype=bool)
+        points1 = np.float32([keypoints1[m.queryIdx].pt for m in matches])
+        points2 = np.float32([keypoints2[m.trainIdx].pt for m in matches])
+        F, mask = vslam_amd.default_context().find_fundamental(points1, points2, thr_px=threshold, prob=0.99)
+        if F is None:  # cv2 returns mask None here and the reference would raise on mask.ravel(); no model -> no inliers
+            return [], np.zeros(len(matches), dtype=bool)
+        return [m for m, inlier in zip(matches, mask) if inlier], mask
 
     def draw_matches(self, img1, keypoints1, img2, keypoints2, matches, flags=0):
         from .types import HAVE_CV2

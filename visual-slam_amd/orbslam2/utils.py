@@ -1,10 +1,8 @@
 """Geometry helpers with the reference's names and signatures (src/orbslam2/utils.py:56-70,120-160), on MI355X.
 
-cv2.findEssentialMat / recoverPose / triangulatePoints are replaced by the HIP two-view kernels.  The essential-matrix
-estimate and the pose recovery are ONE fused native call (mo_init_two_view); calculate_essential_matrix runs it and
-recover_pose returns the pose of that same call (looked up by the point arrays), so the reference's call sequence
-    E, mask = calculate_essential_matrix(p1, p2, K, threshold=3.0); _, R, t, mask_pose = recover_pose(E, p1, p2, K, mask)
-keeps working unchanged.  The I/O helpers of the reference's utils.py (YAML, PLY, undistort) are out of scope."""
+cv2.findEssentialMat / recoverPose / triangulatePoints / findFundamentalMat are replaced by the HIP two-view kernels; every
+function is an independent native call (recover_pose accepts any E, not only the one calculate_essential_matrix returned).
+The YAML / PLY helpers of the reference's utils.py are out of scope; undistort_image is built (mo_undistort)."""
 import numpy as np
 
 import vslam_amd
@@ -13,37 +11,30 @@ RANSAC = 8  # numeric value of cv2.RANSAC, accepted for signature compatibility
 N_HYPOTHESES = 4096
 SEED = 4096
 
-_last = {}
-
-
-def _key(p1, p2, K):
-    return (np.asarray(p1, np.float32).tobytes(), np.asarray(p2, np.float32).tobytes(), np.asarray(K, np.float64).tobytes())
-
-
-def _two_view(points1, points2, camera_matrix, threshold, prob):
-    r = vslam_amd.default_context().init_two_view(points1, points2, camera_matrix, thr_px=threshold, prob=prob,
-                                                  n_hyp=N_HYPOTHESES, seed=SEED)
-    _last.clear()
-    _last[_key(points1, points2, camera_matrix)] = (r, float(threshold))
-    return r
+def undistort_image(image, camera_matrix, distortion):
+    """utils.py:40-52: cv2.undistort(image, camera_matrix, distortion) on the device (grayscale or BGR uint8).  Coefficients beyond
+    (k1, k2, p1, p2, k3) are not supported; the reference's configs hold exactly these five."""
+    d = np.asarray(distortion, np.float64).ravel()
+    if len(d) > 5 and np.any(d[5:] != 0):
+        raise NotImplementedError("only the 5-coefficient model (k1, k2, p1, p2, k3) of the reference's configs is built")
+    return vslam_amd.default_context().undistort(image, camera_matrix, d[:5])
 
 
 def calculate_essential_matrix(points1, points2, camera_matrix, method=RANSAC, prob=0.999, threshold=1.0):
-    r = _two_view(points1, points2, camera_matrix, threshold, prob)
+    """utils.py:120-126.  `method` is accepted for signature compatibility (the device path is the parallel 8-point RANSAC of
+    north_star); `prob` likewise: all N_HYPOTHESES hypotheses are always scored."""
+    r = vslam_amd.default_context().init_two_view(points1, points2, camera_matrix, thr_px=threshold, prob=prob,
+                                                  n_hyp=N_HYPOTHESES, seed=SEED)
     if r["n_good"] == 0 and not np.isfinite(r["E"]).all():
         return None, None
     return r["E"], r["ransac_mask"].astype(np.uint8).reshape(-1, 1)
 
 
 def recover_pose(E, points1, points2, camera_matrix, mask=None):
-    hit = _last.get(_key(points1, points2, camera_matrix))
-    if hit is None or E is None or not np.allclose(hit[0]["E"], E):
-        raise RuntimeError("recover_pose must follow calculate_essential_matrix on the same points (fused native call)")
-    r = hit[0]
-    pm = r["pose_mask"]
-    if mask is not None:
-        pm = pm & (np.asarray(mask).ravel() != 0)
-    return int(pm.sum()), r["R"].copy(), r["t"].copy(), (pm.astype(np.uint8) * 255).reshape(-1, 1)
+    """utils.py:129-134: cv2.recoverPose for ANY essential matrix (mo_recover_pose: decomposition, cheirality vote on the masked
+    points, winner's R, t and mask) -> (n_good, R, t, mask (N, 1) uint8 with 255 for survivors, like cv2)."""
+    r = vslam_amd.default_context().recover_pose(E, points1, points2, camera_matrix, mask)
+    return r["n_good"], r["R"], r["t"], (r["mask"].astype(np.uint8) * 255).reshape(-1, 1)
 
 
 def compute_projection_matrix(R, t, camera_matrix):
@@ -85,3 +76,37 @@ def track_from_last_frame(last_keypoints, last_descriptors, keypoints, descripto
     T[:3, 3] = r["t"].reshape(3)
     inliers = [DMatch(int(q), int(t), 0, float(d)) for (q, t), d, ok in zip(r["sel"], r["sel_dist"], r["inlier"]) if ok]
     return True, T, inliers
+
+
+def calculate_fundamental_matrix(points1, points2, threshold=3.0, prob=0.99):
+    """cv2.findFundamentalMat(points1, points2, cv2.FM_RANSAC, threshold, prob) as the reference calls it (matcher.py:191,
+    local_mapper.py:136) -> (F 3x3 or None, mask (N, 1) uint8 or None)"""
+    F, mask = vslam_amd.default_context().find_fundamental(points1, points2, thr_px=threshold, prob=prob)
+    if F is None:
+        return None, None
+    return F, mask.astype(np.uint8).reshape(-1, 1)
+
+
+def triangulate_new_map_points(prev_keypoints, prev_descriptors, cur_keypoints, cur_descriptors, pose1, pose2, camera_matrix,
+                               ratio=0.8, threshold=3.0):
+    """The geometric core of the reference's LocalMapper._process_new_keyframe (local_mapper.py:116-149): knnMatch(k=2) with the
+    0.8 ratio test -> cv2.findFundamentalMat(FM_RANSAC, 3.0) -> keep inliers -> triangulate with the two keyframe poses.
+    pose1 / pose2: 4x4 keyframe poses.  -> (points_3d (N, 3) float32, inlier matches as DMatch list); ([], []) when fewer than
+    8 ratio-test matches or no fundamental matrix is found (the reference returns early in both cases)."""
+    from .types import DMatch
+    idx, dist, keep = vslam_amd.default_context().match_knn2_ratio(np.uint8(prev_descriptors), np.uint8(cur_descriptors), ratio)
+    two = idx[:, 1] >= 0  # local_mapper.py:123: only pairs with two neighbours take part
+    q = np.flatnonzero(keep & two)
+    if len(q) < 8:
+        return np.zeros((0, 3), np.float32), []
+    points1 = np.float32([prev_keypoints[i].pt for i in q])
+    points2 = np.float32([cur_keypoints[idx[i, 0]].pt for i in q])
+    F, mask = calculate_fundamental_matrix(points1, points2, threshold)
+    if F is None:
+        return np.zeros((0, 3), np.float32), []
+    m = mask.ravel() > 0
+    P1 = compute_projection_matrix(pose1[:3, :3], pose1[:3, 3], camera_matrix)
+    P2 = compute_projection_matrix(pose2[:3, :3], pose2[:3, 3], camera_matrix)
+    pts = convert_to_3d_points(triangulate_points(points1[m], points2[m], P1, P2))
+    matches = [DMatch(int(i), int(idx[i, 0]), 0, float(dist[i, 0])) for i in q[m]]
+    return pts, matches

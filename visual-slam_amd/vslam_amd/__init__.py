@@ -65,8 +65,12 @@ SIGNATURES = {
     "mo_orb_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mo_orb_grid_good_features": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mo_dbg_min_eigen": (_i, [_vp, _vp, _i, _i, _vp]),
+    "mo_undistort": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mo_dev_undistort": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "mo_init_two_view": (_i, [_vp, _vp, _vp, _i, _vp, _d, _d, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mo_recover_pose": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mo_find_fundamental": (_i, [_vp, _vp, _vp, _i, _d, _d, _i, C.c_uint64, _vp, _vp, _vp]),
     "mo_track_pair": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _d, _d, _vp, _d, _i, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                            _vp]),
     "mo_triangulate_points": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -245,6 +249,17 @@ class Context:
         self._check(self.lib.mo_orb_grid_good_features(self.h, _ptr(a), w, h, w * ch, ch, int(n_features), _ptr(xy), C.byref(n)))
         return xy[:n.value].copy()
 
+    def undistort(self, image, K, dist):
+        """cv2.undistort(image, K, dist): (H, W) or (H, W, 3) uint8 -> same shape"""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        ch = 3 if a.ndim == 3 else 1
+        h, w = a.shape[0], a.shape[1]
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        d5 = np.zeros(5); dd = np.asarray(dist, np.float64).ravel(); d5[:min(5, len(dd))] = dd[:5]
+        out = np.empty_like(a)
+        self._check(self.lib.mo_undistort(self.h, _ptr(a), w, h, w * ch, ch, _ptr(Kc), _ptr(d5), _ptr(out)))
+        return out
+
     def dbg_min_eigen(self, gray):
         g = np.ascontiguousarray(gray, np.uint8)
         h, w = g.shape
@@ -284,6 +299,30 @@ class Context:
                                               _ptr(inl), _ptr(X), C.byref(ng)))
         return dict(R=R.reshape(3, 3), t=t.reshape(3, 1), E=E.reshape(3, 3), ransac_mask=ran[:m].astype(bool),
                     pose_mask=inl[:m].astype(bool), X=X[:m], n_good=ng.value)
+
+    def recover_pose(self, E, p1, p2, K, mask=None):
+        """cv2.recoverPose(E, p1, p2, K, mask) for any E -> dict(n_good, R, t, mask (m,) bool, X (m, 3) float32)"""
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        Ec = np.ascontiguousarray(E, np.float64).reshape(9); Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        m = len(p1)
+        mi = None if mask is None else np.ascontiguousarray(np.asarray(mask).ravel() != 0, np.uint8)
+        R = np.zeros(9); t = np.zeros(3); mo = np.zeros(max(m, 1), np.uint8); X = np.zeros((max(m, 1), 3), np.float32); ng = C.c_int(0)
+        self._check(self.lib.mo_recover_pose(self.h, _ptr(Ec), _ptr(p1), _ptr(p2), m, _ptr(Kc), _ptr(mi), _ptr(R), _ptr(t), _ptr(mo),
+                                             _ptr(X), C.byref(ng)))
+        return dict(n_good=ng.value, R=R.reshape(3, 3), t=t.reshape(3, 1), mask=mo[:m].astype(bool), X=X[:m])
+
+    def find_fundamental(self, p1, p2, thr_px=3.0, prob=0.99, n_hyp=4096, seed=4096):
+        """cv2.findFundamentalMat(p1, p2, FM_RANSAC, thr_px, prob) -> (F 3x3 float64 or None, mask (m,) bool)"""
+        p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+        m = len(p1)
+        F = np.zeros(9); mask = np.zeros(max(m, 1), np.uint8); ni = C.c_int(0)
+        self._check(self.lib.mo_find_fundamental(self.h, _ptr(p1), _ptr(p2), m, float(thr_px), float(prob), int(n_hyp),
+                                                 C.c_uint64(int(seed)), _ptr(F), _ptr(mask), C.byref(ni)))
+        if not np.isfinite(F).all():
+            return None, np.zeros(m, bool)
+        return F.reshape(3, 3), mask[:m].astype(bool)
 
     def track_pair(self, kps1, desc1, kps2, desc2, width, height, K, ratio=0.75, disp_frac=0.02, thr_px=1.0, n_hyp=4096,
                    seed=4096):
