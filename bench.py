@@ -124,9 +124,30 @@ def cv2_baseline(frames_u8, n_frames, K):
                                                                   cv2.__version__)}
 
 
+def _baseline_lib():
+    """oracle/_build/libcpu_baseline*.so: rebuilt with -march=native ON this box when a compiler is present (the shipped build
+    targets x86-64-v3 because it is compiled in another container)."""
+    import subprocess
+    odir = os.path.join(ROOT, "oracle")
+    native = os.path.join(odir, "_build", "libcpu_baseline_native.so")
+    flags = "-O3 -march=x86-64-v3 -fopenmp (built in the build container)"
+    path = os.path.join(odir, "_build", "libcpu_baseline.so")
+    try:
+        subprocess.run(["make", "-C", odir, "native"], check=True, capture_output=True, timeout=300)
+        path, flags = native, "-O3 -march=native -fopenmp (built on this box)"
+    except Exception:
+        pass
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.orc_baseline_run.restype = C.c_int
+    lib.orc_baseline_run.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+    return lib, flags
+
+
 def cpu_baseline(frames_u8, n_frames, K):
-    """cv2 itself when the box has it (kind "reference"); otherwise the CPU oracle (own C++/numpy restatement, kind
-    "port") on a bounded sample, 1 core."""
+    """cv2 itself when the box has it (kind "reference"); otherwise the repo's own CPU restatement (kind "port",
+    B4): oracle/cpu_baseline.cpp = the parity oracle's extract + match plus a C++ two-view stage, -O3, one OpenMP thread per host
+    core over frames / pairs, on the SAME batch the GPU step processes; a 1-thread run on a 16-frame sample is reported beside it."""
     try:
         import cv2  # noqa: F401
     except ImportError:
@@ -136,29 +157,28 @@ def cpu_baseline(frames_u8, n_frames, K):
             return cv2_baseline(frames_u8, n_frames, K)
         except Exception as e:  # an unexpected cv2 build: fall back to the port and say so
             print("cv2 baseline failed (%s); timing the CPU restatement instead" % e, file=sys.stderr)
-    from oracle import geom_oracle as G
-    from oracle import orb_oracle as O
-    O.lib().orc_set_variant(0, 0)
-    prm = O.params(nfeatures=NFEAT)
-    t0 = time.perf_counter()
-    feats = [O.detect_and_compute(frames_u8[i], prm) for i in range(n_frames)]
-    t1 = time.perf_counter()
-    matches = []
-    for i in range(n_frames - 1):
-        idx, dist = O.match_knn2(feats[i][1], feats[i + 1][1])
-        matches.append((idx, O.ratio_test(idx, dist, 0.75)))
-    t2 = time.perf_counter()
-    n_pose = min(12, n_frames - 1)
-    for i in range(n_pose):
-        idx, keep = matches[i]
-        p1 = np.stack([feats[i][0]["x"], feats[i][0]["y"]], 1)[keep]
-        p2 = np.stack([feats[i + 1][0]["x"], feats[i + 1][0]["y"]], 1)[idx[keep, 0]]
-        G.init_two_view(p1, p2, K, thr_px=3.0, n_hyp=N_HYP, seed=4096)
-    t3 = time.perf_counter()
-    per_frame = (t1 - t0) / n_frames + (t2 - t1) / max(n_frames - 1, 1) + (t3 - t2) / max(n_pose, 1)
-    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames extract (%.3f s), %d pairs match (%.3f s), %d pairs two-view numpy f64 (%.3f s); "
-                      "own CPU restatement, cv2 unavailable" % (n_frames, t1 - t0, n_frames - 1, t2 - t1, n_pose, t3 - t2)}
+    lib, flags = _baseline_lib()
+    fr = np.ascontiguousarray(frames_u8[:n_frames])
+    Kc = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+
+    def run(n, threads):
+        times = (C.c_double * 3)(); counts = (C.c_longlong * 3)()
+        used = lib.orc_baseline_run(fr.ctypes.data, n, W, H, NFEAT, 0.75, n - 1, Kc.ctypes.data, N_HYP, threads, C.addressof(times),
+                                    C.addressof(counts))
+        return used, list(times), list(counts)
+
+    # one GPU's share of the host: the pool's boxes give a 1-GPU job 16 of the host's cores (a dedicated 8-GPU node would give
+    # each GPU an eighth); os.cpu_count() is reported beside it
+    cores = min(os.cpu_count() or 1, int(os.environ.get("VSLAM_AMD_CPU_THREADS", "16")))
+    used, t, cnt = run(n_frames, cores)
+    n1 = min(16, n_frames)
+    _, t1, _ = run(n1, 1)
+    return {"value": n_frames / sum(t), "unit": "frames/s", "cores": used, "host_cpu_count": os.cpu_count(), "kind": "port",
+            "single_core_value": n1 / sum(t1),
+            "sample": "%d frames: extract %.3f s, %d pairs match %.3f s, %d pairs two-view (C++ f64, %d hyp) %.3f s on %d OpenMP threads; "
+                      "1 thread on %d frames: %.3f s; own CPU restatement (oracle/cpu_baseline.cpp, %s), cv2 unavailable; "
+                      "%d keypoints, %d matches, %d pose inliers"
+                      % (n_frames, t[0], n_frames - 1, t[1], n_frames - 1, N_HYP, t[2], used, n1, sum(t1), flags, cnt[0], cnt[1], cnt[2])}
 
 
 def main():
@@ -166,12 +186,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per rank per step")
+    ap.add_argument("--batch", type=int, default=0, help="frames per rank per step (default: 256 at N = 1 = BASELINE config 3; 512 at "
+                                                        "N > 1, so that 8 ranks process BASELINE config 5's 4096 frames)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches (HIP streams) per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra timing of the opt-in matrix-core matcher")
-    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the batch the CPU baseline is timed on (~10 s)")
+    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the batch the CPU baseline processes (all host cores)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone kernel timing, H2D-inclusive and single-frame legs")
     args = ap.parse_args()
 
     import torch
@@ -194,7 +216,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     from vslam_amd.sharding import gather_map_points, shard
-    B = args.batch
+    B = args.batch if args.batch > 0 else (256 if world == 1 else 512)
     first, nb, n_pairs, _ = shard(rank, world, B)   # rank > 0 re-extracts the frame preceding its shard (halo)
     pairs_all = [shard(r, world, B)[2] for r in range(world)]
     frames = make_frames(torch, dev, first, nb)
@@ -211,7 +233,7 @@ def main():
         latency-bound kernels of one sub-batch (selection replay, two-view refit) overlap the VALU-bound ones of
         the other."""
 
-        def __init__(self, p0, p1):
+        def __init__(self, p0, p1, src=None):
             self.p0, self.p1, n = p0, p1, p1 - p0 + 1
             self.stream = torch.cuda.Stream(device=dev)
             self.ctx = V.Context(device=local, max_w=W, max_h=H, max_batch=n)
@@ -224,7 +246,7 @@ def main():
             self.mpass = torch.zeros((n - 1, CAP), dtype=torch.uint8, device=dev)
             self.pose = torch.zeros((n - 1, 12), dtype=torch.float64, device=dev)
             io = V.BatchIO()
-            io.d_gray = frames[p0:].data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
+            io.d_gray = (frames if src is None else src)[p0:].data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
             io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = N_HYP; io.seed = 4096
             for i in range(9):
                 io.K[i] = float(K.reshape(9)[i])
@@ -282,22 +304,45 @@ def main():
         cnt = torch.cat([sb.counts for sb in subs]).cpu().numpy()
         npt = npts[:n_pairs].cpu().numpy()
         mpass_mean = float(torch.cat([sb.mpass for sb in subs]).sum(dim=1).float().mean().item())
-        # roofline of the dominant kernel (largest share of device time), algorithmic bytes / measured duration
         per_stage = {k: v / args.steps for k, v in stage_acc.items()}
-        dom = max(per_stage, key=per_stage.get)
         n_ext = sum(sb.io.batch for sb in subs)  # frames extracted per step (sub-batches share one frame each)
-        units = n_pairs if dom in ("match_knn2_ratio", "two_view") else n_ext
-        alg_bytes = STAGE_BYTES.get(dom, 0) * units
-        achieved = alg_bytes / (per_stage[dom] * 1e-3) / 1e9 if per_stage[dom] > 0 else 0.0
-        total_alg = sum(STAGE_BYTES.get(k, 0) * (n_pairs if k in ("match_knn2_ratio", "two_view") else n_ext) for k in per_stage)
-        traffic = None  # HBM bytes per step of the dominant stage from the committed PMC passes (same command, batch 256)
+        units_of = lambda k: n_pairs if k in ("match_knn2_ratio", "two_view") else n_ext
+        total_alg = sum(STAGE_BYTES.get(k, 0) * units_of(k) for k in per_stage)
+        # Stand-alone kernel times: in the timed region the blur runs on a low-priority stream BESIDE fast_nms + select_harris,
+        # so those three spans are stretched by one another.  A few extra steps on a second context with the blur serialised
+        # (VSLAM_AMD_SERIAL_BLUR=1; "fast_nms" then spans blur + FAST on one stream) give each kernel's own duration.
+        alone = None
+        if world == 1 and S == 1 and not args.no_extras:
+            os.environ["VSLAM_AMD_SERIAL_BLUR"] = "1"
+            try:
+                sbs = SubBatch(0, n_pairs)
+            finally:
+                os.environ.pop("VSLAM_AMD_SERIAL_BLUR", None)
+            acc = {}
+            for it in range(3 + 10):
+                sbs.launch()
+                torch.cuda.synchronize()
+                if it >= 3:
+                    for name, ms in sbs.ctx.stage_times():
+                        acc[name] = acc.get(name, 0.0) + ms / 10
+            alone = dict(acc)
+            alone["fast_nms"] = acc["fast_nms"] - acc["blur"]
+            sbs.ctx.close()
+        # roofline of the kernel on the critical path with the largest stand-alone time among the image kernels: k_fast
+        crit = "fast_nms"
+        crit_ms = alone[crit] if alone else per_stage[crit]
+        alg_bytes = STAGE_BYTES[crit] * n_ext
+        achieved = alg_bytes / (crit_ms * 1e-3) / 1e9
+        pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_per_kernel.json")) as f:
                 pmc = json.load(f)
-            if pmc.get("batch_frames") == B and S == 1 and dom in pmc["per_stage"]:
-                traffic = pmc["per_stage"][dom]["hbm_bytes"]
         except Exception:
-            traffic = None
+            pmc = {}
+        kf = pmc.get("kernels", {}).get("k_fast", {}) if pmc.get("batch_frames") == B else {}
+        traffic = kf.get("hbm_bytes")  # FETCH_SIZE x 2 (guide: 16-byte-per-lane streams count half) + WRITE_SIZE, per launch
+        valu = kf.get("valu_insts")    # SQ_INSTS_VALU per launch (wave instructions)
+        valu_frac = valu * 2.0 / (crit_ms * 1e-3 * 2.4e9 * 1024) if valu else None  # 2 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz
         out = {
             "metric": metric_name(),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -310,13 +355,18 @@ def main():
                        "keypoints_per_frame_mean": float(cnt.mean()), "matches_per_pair_mean": mpass_mean,
                        "map_points_per_pair_mean": float(npt.mean()),
                        "parallelism": "frame-sharded x%d, RCCL gather of map points" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / PEAK_HBM_GBPS, 5), "traffic": traffic,
-                         "algorithmic_bytes": alg_bytes,
-                         "kernel_ms": round(per_stage[dom], 4),
+            "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / PEAK_HBM_GBPS, 5), "hbm_frac": round(achieved / PEAK_HBM_GBPS, 5),
+                         "valu_frac": round(valu_frac, 4) if valu_frac else None, "traffic": traffic,
+                         "algorithmic_bytes": alg_bytes, "kernel_ms": round(crit_ms, 4),
+                         "kernel_ms_source": "stand-alone (blur serialised)" if alone else "hipEvent span in the timed region",
                          "pipeline_achieved": round(total_alg / (ms_step * 1e-3) / 1e9, 2),
-                         "note": "algorithmic bytes (SURVEY 8d) of the dominant stage / its hipEvent time; the path is "
-                                 "integer-VALU / latency bound, far from the HBM roof (see DESIGN.md)"},
+                         "note": "k_fast = the longest stand-alone kernel on the critical path; algorithmic bytes (SURVEY 8d: "
+                                 "950 532 B per frame) / its own duration.  valu_frac = SQ_INSTS_VALU (profiles/r02_pmc_per_kernel.json) "
+                                 "x 2 cycles / (1024 SIMDs x 2.4 GHz x duration); tools/ubench.hip measures 2.3 cycles only for add/sub/"
+                                 "logic/shift-right/f32 add-mul and 4.5 for every other vector instruction at the occupancy these "
+                                 "kernels run at, so an integer kernel tops out near 0.5 on this scale (DESIGN.md 4)"},
+            "stage_ms_standalone": {k: round(v, 4) for k, v in alone.items()} if alone else None,
             "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
         }
         # Opt-in variant, timed outside the headline region on the same inputs: the matrix-core matcher
@@ -349,6 +399,52 @@ def main():
                                                       "peak": 5000.0, "unit": "TOP/s", "frac": round(tops / 5000.0, 4),
                                                       "dtype": "int8"}}
             sb2.ctx.close()
+        if world == 1 and S == 1 and not args.no_extras:
+            # (a) PCIe-inclusive rate: every step first copies its frames from pinned host memory into HBM on the same stream
+            #     (307 200 B per frame over Gen5 x16); never the headline value
+            host = torch.empty((nb, H, W), dtype=torch.uint8).pin_memory()
+            host.copy_(frames.cpu())
+            dev_buf = torch.empty_like(frames)
+            sb3 = SubBatch(0, n_pairs, src=dev_buf)
+            def h2d_step():
+                with torch.cuda.stream(sb3.stream):
+                    dev_buf.copy_(host, non_blocking=True)
+                sb3.launch()
+            for _ in range(max(1, args.warmup)):
+                h2d_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                h2d_step()
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t1
+            out["h2d_inclusive"] = {"value": round(B * args.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 3),
+                                    "note": "pinned host -> HBM copy of the batch (%.1f MB) inside every step" % (nb * H * W / 1e6)}
+            sb3.ctx.close()
+            # (b) single-frame latency through the drop-in classes, host arrays in and Python objects out: what the reference's
+            #     Tracker would see per call (BASELINE config 2; extract_features(distributed=True) is Tracker's default path)
+            from orbslam2.extractor import ORBExtractor
+            from orbslam2.matcher import DescriptorMatcher
+            f0, f1 = frames[0].cpu().numpy(), frames[1].cpu().numpy()
+            ex = ORBExtractor(n_features=NFEAT)
+            mt = DescriptorMatcher("bruteforce-hamming", ratio_threshold=0.75)
+            def med_ms(fn, n):
+                fn()
+                ts = []
+                for _ in range(n):
+                    t = time.perf_counter(); fn(); ts.append((time.perf_counter() - t) * 1e3)
+                return round(sorted(ts)[len(ts) // 2], 3)
+            (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
+            import vslam_amd as V2
+            ctx1 = V2.default_context()
+            out["single_frame_ms"] = {
+                "detect_and_compute": med_ms(lambda: ex.detect_and_compute(f0), 20),
+                "detect_and_compute_native_arrays": med_ms(lambda: ctx1.orb_detect_compute(f0, ex.orb.prm), 20),
+                "match_2000x2000": med_ms(lambda: mt.match(d0, d1), 20),
+                "match_native_arrays": med_ms(lambda: ctx1.match_knn2_ratio(d0, d1, 0.75), 20),
+                "extract_features_distributed": med_ms(lambda: ex.extract_features(f0, distributed=True), 10),
+                "note": "median wall ms per call, host numpy in / Python objects out (H2D + kernels + D2H + sync); the *_native_arrays "
+                        "rows stop at numpy arrays (no KeyPoint / DMatch objects)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames].cpu().numpy(), args.cpu_frames, K)
         print(json.dumps(out), flush=True)
