@@ -248,6 +248,7 @@ def main():
             io = V.BatchIO()
             io.d_gray = (frames if src is None else src)[p0:].data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
             io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = N_HYP; io.seed = 4096
+            io.pair_index_base = first + p0  # global pair index of this sub-batch's pair 0
             for i in range(9):
                 io.K[i] = float(K.reshape(9)[i])
             io.d_kps = self.kps.data_ptr(); io.d_desc = self.desc.data_ptr(); io.d_counts = self.counts.data_ptr()

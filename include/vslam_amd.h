@@ -136,7 +136,7 @@ int mo_find_fundamental(mo_ctx*, const float* p1, const float* p2, int m, double
 /* One tracking step of Tracker._track_from_last_frame (tracker.py:214-254) for a single frame pair, host in / host out:
  * matcher.match(prev, cur) -> displacement filter (matcher.py:109-142, frac = 0.02 of (w + h) / 2) -> 2 x median distance
  * filter (matcher.py:144-169) -> cv2.findEssentialMat(RANSAC, 0.999, thr_px = 1.0) -> cv2.recoverPose, all on the device.
- * kps1/desc1 = previous frame (query), kps2/desc2 = current frame (train); ratio <= 0 disables the ratio test.
+ * kps1/desc1 = previous frame (query), kps2/desc2 = current frame (train); a negative ratio disables the ratio test.
  * sel_idx [min(n1, 4096)][2] (queryIdx, trainIdx) and sel_dist receive the kept matches in the reference's order (ascending
  * distance, ties in query order), n_sel their number; inlier [n_sel] the recoverPose mask per kept match.  With fewer than 8
  * kept matches (tracker.py:234) R, t, E are NaN and n_inliers = 0. */
@@ -157,7 +157,7 @@ typedef struct {
     const uint8_t* d_gray;  /* [batch][h][w] u8, device */
     int32_t w, h, batch;
     int32_t cap;            /* keypoint capacity per frame */
-    double ratio;           /* Lowe ratio, <= 0 disables the test */
+    double ratio;           /* Lowe ratio; a NEGATIVE value disables the test (0.0 is a threshold: nothing with two neighbours passes) */
     double K[9];            /* intrinsics for the two-view stage */
     double thr_px;          /* RANSAC threshold (initializer.py:79 passes 3.0) */
     int32_t n_hyp;          /* hypotheses per pair, 0 = skip the two-view stage */
@@ -182,6 +182,9 @@ typedef struct {
     int32_t* d_sel_dist;    /* MO_MODE_TRACK: [batch-1][cap] their Hamming distances; may be NULL */
     int32_t* d_sel_n;       /* MO_MODE_TRACK: [batch-1] number of kept matches */
     uint8_t* d_pose_mask;   /* either mode, may be NULL: [batch-1][cap] recoverPose mask per QUERY keypoint */
+    uint64_t pair_index_base; /* global index of this batch's pair 0 when a longer sequence is sharded over calls / ranks: the
+                               RANSAC sampling stream of a pair is a function of (seed, global pair index), so the result
+                               of a pair does not depend on how the sequence was cut */
 } mo_batch_io;
 
 #define MO_MODE_INIT 0
@@ -193,9 +196,24 @@ int mo_dev_frontend_batch(mo_ctx*, const mo_orb_params*, const mo_batch_io*);
 int mo_dev_orb_detect_compute(mo_ctx*, const mo_orb_params*, const uint8_t* d_gray, int w, int h, int batch,
                               mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts);
 /* pairs: q/t frame indices into d_desc [*][cap][32] with per-frame counts d_counts */
+/* ratio < 0 disables the ratio test */
 int mo_dev_match_pairs(mo_ctx*, const uint8_t* d_desc, const int32_t* d_counts, int cap, const int32_t* d_qf,
                        const int32_t* d_tf, int n_pairs, double ratio, int32_t* d_idx, int32_t* d_dist,
                        uint8_t* d_pass);
+
+/* ---- multi-GPU: the final map-point gather (SURVEY.md 8b mo_gather_map_points, 8e) --------------------------------------
+ * One process per GPU, each with its own context; frames are sharded contiguously and nothing is exchanged on the data path.
+ * The only collective is this padded gather of the per-pair map points to `root` over RCCL (bound with dlopen at first use).
+ *   mo_comm_unique_id : rank 0 creates the 128-byte id; the host program hands it to the other ranks (any channel)
+ *   mo_comm_init      : ncclCommInitRank on the context's device; mo_comm_destroy (also done by mo_destroy)
+ *   mo_gather_map_points: d_local [rows_max][cap][3] f32 of this rank (rows_local valid rows), d_all on root
+ *                       [world][rows_max][cap][3], d_rows_all [world] int32 on every rank; device pointers, enqueued on the
+ *                       context stream, no host synchronisation. */
+int mo_comm_unique_id(uint8_t id[128]);
+int mo_comm_init(mo_ctx*, const uint8_t id[128], int rank, int world);
+int mo_comm_destroy(mo_ctx*);
+int mo_gather_map_points(mo_ctx*, const float* d_local, int rows_local, int rows_max, int cap, int root, float* d_all,
+                         int32_t* d_rows_all);
 
 /* Status of the mo_dev_* calls enqueued since the last mo_dev_status: the kernels never fault on overflow, they clamp and
  * raise a bit.  Synchronises the context stream, copies the flag word to flags[0] (flags may be NULL; [1..3] reserved, 0)

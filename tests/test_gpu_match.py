@@ -34,7 +34,7 @@ def _check(ctx, q, t, ratio):
 
 
 @pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (5, 1), (1, 7), (257, 513), (2000, 3)])
-@pytest.mark.parametrize("ratio", [0.75, 0.85, None])
+@pytest.mark.parametrize("ratio", [0.75, 0.85, 0.0, None])  # 0.0 is a threshold (nothing with two neighbours passes), None = test off
 def test_random_descriptors(ctx, nq, nt, ratio):
     rng = np.random.default_rng(nq * 131 + nt)
     _check(ctx, rng.integers(0, 256, (nq, 32), dtype=np.uint8), rng.integers(0, 256, (nt, 32), dtype=np.uint8), ratio)

@@ -300,7 +300,7 @@ extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const ui
     if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, t, (size_t)batch * nt * 32, hipMemcpyHostToDevice, c->stream));
     mo_stage_begin(c);
     rc = match_launch_pairs(c, c->d_mq, c->d_mt, (size_t)nq * 32, (size_t)nt * 32, nullptr, nullptr, nullptr, nq, nt, batch,
-                            nq, ratio ? *ratio : 0.0, c->d_midx, c->d_mdist, c->d_mpass);
+                            nq, ratio ? *ratio : -1.0, c->d_midx, c->d_mdist, c->d_mpass);
     if (rc) return rc;
     mo_stage_mark(c, "match_knn2_ratio");
     HIPCHK(c, hipMemcpyAsync(train_idx, c->d_midx, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
@@ -607,7 +607,7 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
         std::memset(&a, 0, sizeof(a));
         a.n_pairs = n_pairs; a.cap = io->cap; a.n_hyp = io->n_hyp;
         for (int i = 0; i < 9; i++) a.K[i] = io->K[i];
-        a.thr_px = io->thr_px; a.seed = io->seed;
+        a.thr_px = io->thr_px; a.seed = io->seed; a.pair_base = io->pair_index_base;
         a.d_kps = io->d_kps; a.d_counts = io->d_counts; a.d_match_idx = io->d_match_idx; a.d_match_pass = io->d_match_pass;
         a.d_pose = io->d_pose; a.d_points = io->d_points; a.d_n_points = io->d_n_points; a.d_inlier = io->d_pose_mask;
         if (io->mode == MO_MODE_TRACK) {

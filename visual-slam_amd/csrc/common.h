@@ -87,6 +87,7 @@ struct mo_ctx {
     uint32_t* d_tile_tab = nullptr; int n_tile_tab = 0;    // blur: tile -> level | tile column << 8 | tile row << 20 (built with the plan)
     int tile_cum[MO_MAX_LEVELS + 1] = {};                  // tiles of levels < L (the table is level-major: a prefix blurs the first levels)
     uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
+    int* d_lv_tab = nullptr;       // k_describe: per-level geometry table (built with the plan)
     int* d_flags = nullptr;        // [4] error flags raised by kernels
     unsigned lds_attr_done = 0;    // bit per kernel whose max-dynamic-LDS attribute has been raised on this device
     // output staging for the host API
@@ -98,6 +99,9 @@ struct mo_ctx {
     void* d_tv = nullptr; size_t tv_bytes = 0;
     // generic temp
     void* d_tmp = nullptr; size_t tmp_bytes = 0;
+
+    // RCCL communicator of the sharded batched mode (comm.hip); null until mo_comm_init
+    void* comm = nullptr; int comm_rank = 0, comm_world = 1;
 
     // stage timing
     hipEvent_t ev[MO_NSTAGES + 1] = {};
@@ -156,6 +160,7 @@ struct TwoViewArgs {
                 // 1: fundamental matrix (pixel coordinates, Hartley-normalised with one common scale): F in d_E, mask in d_ransac
     double K[9], thr_px;
     uint64_t seed;
+    uint64_t pair_base;  // global index of pair 0 (sharded batches): the sampling stream of a pair depends on its global index only
     // per pair: matches are read from the matcher outputs + keypoints, or from explicit point arrays
     const mo_keypoint* d_kps; const int32_t* d_counts; const int32_t* d_match_idx; const uint8_t* d_match_pass;
     const int32_t* d_sel; const int32_t* d_sel_n;  // tracking mode: [pairs][cap][2] (queryIdx, trainIdx) in the caller's order + counts;

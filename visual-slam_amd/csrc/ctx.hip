@@ -83,7 +83,8 @@ static void free_plan_buffers(mo_ctx* c) {
         if (t.xofs) hipFree(t.xofs);
         t = ResizeTab();
     }
-    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab, c->d_strip_tab};
+    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab, c->d_strip_tab, c->d_lv_tab};
+    c->d_lv_tab = nullptr;
     for (void* b : bufs) if (b) hipFree(b);
     c->d_tile_tab = c->d_strip_tab = nullptr; c->n_tile_tab = c->n_strip_tab = 0;
     c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_strip_cnt = nullptr; c->d_scratch = nullptr;
@@ -96,6 +97,7 @@ extern "C" void mo_destroy(mo_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    mo_comm_destroy(c);
     free_plan_buffers(c);
     void* bufs[] = {c->d_in, c->d_gray, c->d_flags, c->d_kps, c->d_desc, c->d_counts, c->d_mq, c->d_mt,
                     c->d_midx, c->d_mdist, c->d_mpass, c->d_tv, c->d_tmp};

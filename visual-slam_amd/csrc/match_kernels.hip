@@ -22,10 +22,11 @@ __device__ __forceinline__ void emit_match(int i0, int d0, int i1, int d1, doubl
     oidx[2 * o] = i0; oidx[2 * o + 1] = i1;
     odist[2 * o] = d0; odist[2 * o + 1] = d1;
     // matcher.py:73-81: len(match) >= 2 -> m.distance < ratio * n.distance (Python floats = IEEE double);
-    // one neighbour only -> kept; ratio <= 0 encodes ratio_test=False
+    // one neighbour only -> kept; a NEGATIVE ratio encodes ratio_test=False (0.0 is a valid threshold: like the reference's
+    // strict '<' it lets nothing with two neighbours through)
     uint8_t pass;
     if (i0 < 0) pass = 0;
-    else if (i1 < 0 || !(ratio > 0.0)) pass = 1;
+    else if (i1 < 0 || ratio < 0.0) pass = 1;
     else pass = ((double)d0 < ratio * (double)d1) ? 1 : 0;
     opass[o] = pass;
 }

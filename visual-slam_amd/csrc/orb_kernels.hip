@@ -870,6 +870,15 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
     if ((lane & 1) == 0) desc[lane >> 1] = (uint8_t)(nib | (hi << 4));
 }
 
+// per-level table of k_describe (device copy built with the plan): the LevelInfo fields it needs, as ints
+#define DLV_N 8
+#define DLV_PITCH 0
+#define DLV_OFF 1
+#define DLV_BPITCH 2
+#define DLV_BOFF 3
+#define DLV_FIN_OFF 4
+#define DLV_SCALE 5
+
 #define DP_RAW_PITCH 36   // 31 columns + <= 3 alignment lead-in, 9 dwords
 #define DP_BLR_PITCH 44   // 39 columns + <= 3 alignment lead-in, 11 dwords
 #define DP_PATCH_BYTES (39 * DP_BLR_PITCH)  // one LDS patch per keypoint: first the raw 31x31 window, then the blurred 39x39 one
@@ -982,23 +991,35 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
                                                   const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                                   const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
                                                   uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
-                                                  int* flags) {
+                                                  int* flags, const int* __restrict__ lv_tab, uint32_t inv_per) {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_PATCH_BYTES];
+    __shared__ int s_lv[MO_MAX_LEVELS][DLV_N];
     // XCD affinity (speed only, any mapping is correct): consecutive workgroup ids go round-robin to the 8 XCDs, each with
     // its own L2.  Re-indexing so that all workgroups of a frame share one id residue keeps the frame's two pyramids
     // (2 MB) in ONE L2 while its keypoints are described, instead of being fetched into eight.
     int frame = blockIdx.y, wg = blockIdx.x;
     if ((gridDim.y & 7) == 0) {
-        const int lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
-        frame = (lin & 7) + 8 * (n / (int)gridDim.x);
-        wg = n % (int)gridDim.x;
+        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
+        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / gridDim.x by the host's reciprocal (0: one per frame)
+        frame = (int)((lin & 7) + 8 * q);
+        wg = (int)(n - q * gridDim.x);
     }
     const int grp = threadIdx.x / DG, gl = threadIdx.x % DG;
     const int k = wg * DK_PER_WG + grp;
+    // The kernel is bound by its chain of DEPENDENT memory round trips times the few keypoints a CU holds in flight (round 1: a
+    // scalar load + wait per level to find the keypoint's level, then the level's geometry out of the kernel arguments, then
+    // the keypoint record, then the patches: ~11 round trips).  Now: the per-level counts of the frame (wave-uniform, all
+    // issued at once) and the level table (copied to LDS) travel together, then the record, then the patches: 3.
+    if (threadIdx.x < MO_MAX_LEVELS * DLV_N) (&s_lv[0][0])[threadIdx.x] = lv_tab[threadIdx.x];
     const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
+    int cn[MO_MAX_LEVELS];
+#pragma unroll
+    for (int l = 0; l < MO_MAX_LEVELS; l++) cn[l] = fc[l];  // (entries past nlevels are ignored below)
+    __syncthreads();
     int total = 0, L = -1, idx = 0;
-    for (int l = 0; l < P.nlevels; l++) {
-        int n = fc[l];
+#pragma unroll
+    for (int l = 0; l < MO_MAX_LEVELS; l++) {
+        const int n = l < P.nlevels ? cn[l] : 0;
         if (L < 0 && k < total + n) { L = l; idx = k - total; }
         total += n;
     }
@@ -1008,11 +1029,13 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
     }
     if (L < 0 || k >= cap) return;  // uniform within the group; no barriers below
     uint8_t* s_p = s_patch + grp * DP_PATCH_BYTES;
-    const LevelInfo lv = P.lv[L];
+    struct { int pitch, off, bpitch, boff, fin_off; float scale; } lv;  // the level's geometry from the LDS copy of the table
+    lv.pitch = s_lv[L][DLV_PITCH]; lv.off = s_lv[L][DLV_OFF]; lv.bpitch = s_lv[L][DLV_BPITCH]; lv.boff = s_lv[L][DLV_BOFF];
+    lv.fin_off = s_lv[L][DLV_FIN_OFF]; lv.scale = __int_as_float(s_lv[L][DLV_SCALE]);
     const FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
     const int x = fk.x, y = fk.y;
     const float px = (float)x * lv.scale, py = (float)y * lv.scale;
-    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    const uint8_t* img = L == 0 ? gray + (size_t)frame * P.w * P.h : pyr + (size_t)frame * P.pyr_stride + lv.off;
     // aligned 9-dword (11-dword) window start, moved left when it would cross the end of the row
     const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0 && lv.pitch >= 36;
     const int xr0 = al_raw ? min((x - 15) & ~3, lv.pitch - 36) : (x - 15) & ~3, offr = (x - 15) - xr0;
@@ -1070,12 +1093,23 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
                         int* d_counts) {
     const Plan& P = c->plan;
     const dim3 grid((cap + DK_PER_WG - 1) / DK_PER_WG, batch);
+    if (!c->d_lv_tab) {  // (re)built with the plan: free_plan_buffers drops it
+        int tab[MO_MAX_LEVELS * DLV_N] = {0};
+        for (int L = 0; L < P.nlevels; L++) {
+            int* e = tab + L * DLV_N;
+            e[DLV_PITCH] = P.lv[L].pitch; e[DLV_OFF] = P.lv[L].off; e[DLV_BPITCH] = P.lv[L].bpitch; e[DLV_BOFF] = P.lv[L].boff;
+            e[DLV_FIN_OFF] = P.lv[L].fin_off; std::memcpy(&e[DLV_SCALE], &P.lv[L].scale, sizeof(float));
+        }
+        HIPCHK(c, hipMalloc((void**)&c->d_lv_tab, sizeof(tab)));
+        HIPCHK(c, hipMemcpy(c->d_lv_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    }
+    const uint32_t inv_per = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
     if (d_desc)
         hipLaunchKernelGGL(k_describe<true>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
-                           d_kps, d_desc, cap, d_counts, c->d_flags);
+                           d_kps, d_desc, cap, d_counts, c->d_flags, c->d_lv_tab, inv_per);
     else
         hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
-                           d_kps, d_desc, cap, d_counts, c->d_flags);
+                           d_kps, d_desc, cap, d_counts, c->d_flags, c->d_lv_tab, inv_per);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     bool valid = h < a.n_hyp;
     if (valid) {
         int idx[8];
-        sample8(a.seed + (uint64_t)pair * 0x632BE59BD9B4E019ull, h, m, idx);
+        sample8(a.seed + ((uint64_t)pair + a.pair_base) * 0x632BE59BD9B4E019ull, h, m, idx);  // GLOBAL pair index: results do not depend on the sharding
         double pts[32];
         for (int k = 0; k < 8; k++)
             for (int j = 0; j < 4; j++) pts[k * 4 + j] = xn[(size_t)idx[k] * 4 + j];

@@ -46,7 +46,7 @@ class BatchIO(C.Structure):
                 ("d_match_dist", C.c_void_p), ("d_match_pass", C.c_void_p), ("d_pose", C.c_void_p),
                 ("d_points", C.c_void_p), ("d_n_points", C.c_void_p),
                 ("mode", C.c_int32), ("disp_frac", C.c_double), ("d_sel_idx", C.c_void_p), ("d_sel_dist", C.c_void_p),
-                ("d_sel_n", C.c_void_p), ("d_pose_mask", C.c_void_p)]
+                ("d_sel_n", C.c_void_p), ("d_pose_mask", C.c_void_p), ("pair_index_base", C.c_uint64)]
 
 
 MODE_INIT, MODE_TRACK = 0, 1
@@ -78,6 +78,10 @@ SIGNATURES = {
     "mo_dev_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mo_dev_match_pairs": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     "mo_dev_status": (_i, [_vp, _vp]),
+    "mo_comm_unique_id": (_i, [_vp]),
+    "mo_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "mo_comm_destroy": (_i, [_vp]),
+    "mo_gather_map_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
     "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dbg_fast_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
@@ -189,6 +193,24 @@ class Context:
         if rc not in (MO_OK, MO_ERR_CAPACITY):
             self._check(rc)
         return int(f[0])
+
+    # ---- multi-GPU gather through the C-ABI (RCCL); the id travels between ranks by the caller's own channel ------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.mo_comm_unique_id(buf)
+        if rc != MO_OK:
+            raise NativeUnavailable("RCCL could not be loaded (mo_comm_unique_id returned %d)" % rc)
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.mo_comm_init(self.h, buf, int(rank), int(world)))
+
+    def gather_map_points(self, d_local_ptr, rows_local, rows_max, cap, root, d_all_ptr, d_rows_all_ptr):
+        self._check(self.lib.mo_gather_map_points(self.h, C.c_void_p(d_local_ptr), int(rows_local), int(rows_max), int(cap), int(root),
+                                                  C.c_void_p(d_all_ptr) if d_all_ptr else None, C.c_void_p(d_rows_all_ptr)))
 
     def stage_times(self):
         names = C.POINTER(C.c_char_p)()
@@ -337,7 +359,7 @@ class Context:
         sel = np.zeros((max(n1, 1), 2), np.int32); sd = np.zeros(max(n1, 1), np.int32); inl = np.zeros(max(n1, 1), np.uint8)
         ns, ni = C.c_int(0), C.c_int(0)
         self._check(self.lib.mo_track_pair(self.h, _ptr(k1), n1, _ptr(d1), _ptr(k2), n2, _ptr(d2), int(width), int(height),
-                                           float(ratio if ratio is not None else 0.0), float(disp_frac), _ptr(Kc), float(thr_px),
+                                           float(ratio if ratio is not None else -1.0), float(disp_frac), _ptr(Kc), float(thr_px),
                                            int(n_hyp), C.c_uint64(int(seed)), _ptr(R), _ptr(t), _ptr(E), _ptr(sel), _ptr(sd),
                                            C.byref(ns), _ptr(inl), C.byref(ni)))
         n = ns.value
