@@ -11,9 +11,11 @@
 //   k_tv_hyp     one thread per hypothesis: counter-based 8-sample, 8x9 null vector by Householder QR (registers),
 //                projection on the essential manifold (3x3 SVD via Jacobi), MSAC cost (truncated Sampson distance)
 //                over the FIRST QUARTER of the correspondences, which arrive as scalar operands; the block's most
-//                promising hypothesis is scored completely -> upper bound of the pair's best cost
-//   k_tv_compact / k_tv_score   hypotheses whose partial cost already exceeds the bound cannot win; the others (about a
-//                fifth) are listed and finished, 64 per wavefront -> exact argmin, one atomicMin per wavefront
+//                promising hypothesis is scored completely -> an upper bound of the pair's best cost; hypotheses whose
+//                partial cost already exceeds it cannot win, only the others (about a fifth) are written out, compacted
+//                (round 1 materialised all 4096 x 9 doubles per pair and every partial cost: 135 MB per step; now ~25 MB)
+//   k_tv_tasks / k_tv_score   the survivors of the whole launch are cut into tasks of 64 (dense table: busy wavefronts first,
+//                evenly spread over the chip) and finished, one per lane -> exact argmin, one atomicMin per wavefront
 //   k_tv_finish  one block per pair: consensus set of the best hypothesis -> adaptive-threshold least-squares
 //                8-point refits (9x9 normal matrix, inverse iteration) -> final inliers -> decompose E -> cheirality
 //                vote over the 4 (R, t) candidates with per-point DLT -> final DLT triangulation in pixel space
@@ -25,48 +27,47 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define TVF_BLOCK 512  // k_tv_finish: one block per pair, about one correspondence per thread in the per-point phases
 
+#define TV_REC 11  // doubles per survivor record: E (9), partial cost, hypothesis index (as its bit pattern)
+
 struct TvWork {
     double* xn;        // [pairs][cap][4] normalised x1,y1,x2,y2
     float* px;         // [pairs][cap][4] pixel u1,v1,u2,v2
     int* qidx;         // [pairs][cap] query keypoint index of correspondence i
     int* m;            // [pairs]
-    double* hypE;      // [pairs][n_hyp][9]
-    unsigned long long* best;  // [pairs] (float32 bits of the MSAC cost << 32) | hypothesis index, minimum wins
-    double* part;      // [pairs][n_hyp] MSAC cost over the first tv_first(m) correspondences (staged scoring)
-    unsigned* bound;   // [pairs] float32 bits of an upper bound of the best total cost (staged scoring)
-    unsigned short* list;  // [pairs][n_hyp] hypotheses that survive the bound (any order)
-    int* n_alive;      // [pairs]
+    double* surv;      // [pairs][n_hyp][TV_REC] survivors of the first scoring stage, dense from index 0 (any order)
+    int* n_alive;      // [pairs] survivors listed so far
     int* n_tasks;      // [1] number of 64-survivor tasks of the whole launch
-    int2* task;        // [pairs * ceil(n_hyp / 64)] (pair, first survivor) of each task, dense from index 0
+    int2* task;        // [pairs * ceil(n_hyp / 64)] (pair, task of the pair) of each task, dense from index 0
+    unsigned long long* wkey;  // [pairs][ceil(n_hyp / 64)] best key of each k_tv_score wavefront (or k_tv_hyp block when unstaged)
+    double* wE;        // [pairs][ceil(n_hyp / 64)][9] its matrix: k_tv_finish takes the one whose key equals best
+    unsigned long long* best;  // [pairs] (float32 bits of the MSAC cost << 32) | hypothesis index, minimum wins
     double* norm;      // [pairs][8] fundamental-matrix model: common scale s, centroid 1 (x, y), centroid 2 (x, y) of the
                        // Hartley normalisation x_n = s (x - c); Sampson distances scale by s^2, so thr_n = thr_px * s
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
-    size_t p = (size_t)n_pairs;
-    return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 +
-           p * (size_t)n_hyp * 9 * sizeof(double) + p * sizeof(unsigned long long) + p * (size_t)n_hyp * sizeof(double) +
-           p * sizeof(unsigned) + p * (size_t)n_hyp * sizeof(unsigned short) + p * sizeof(int) + 16 +
-           p * (size_t)((n_hyp + 63) / 64) * sizeof(int2) + p * 8 * sizeof(double) + 1024;
+    size_t p = (size_t)n_pairs, nt = (size_t)((n_hyp + 63) / 64);
+    return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 + 16 +
+           p * (size_t)n_hyp * TV_REC * sizeof(double) + p * nt * (sizeof(int2) + sizeof(unsigned long long) + 9 * sizeof(double)) +
+           p * sizeof(unsigned long long) + p * 8 * sizeof(double) + 1024;
 }
 
 static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     TvWork w;
     uint8_t* b = (uint8_t*)base;
-    size_t p = (size_t)n_pairs;
+    size_t p = (size_t)n_pairs, nt = (size_t)((n_hyp + 63) / 64);
     w.xn = (double*)b; b += p * cap * 4 * sizeof(double);
-    w.hypE = (double*)b; b += p * (size_t)n_hyp * 9 * sizeof(double);
+    w.surv = (double*)b; b += p * (size_t)n_hyp * TV_REC * sizeof(double);
+    w.wE = (double*)b; b += p * nt * 9 * sizeof(double);
+    w.wkey = (unsigned long long*)b; b += p * nt * sizeof(unsigned long long);
     w.best = (unsigned long long*)b; b += p * sizeof(unsigned long long);
-    w.part = (double*)b; b += p * (size_t)n_hyp * sizeof(double);
     w.norm = (double*)b; b += p * 8 * sizeof(double);
+    w.task = (int2*)b; b += p * nt * sizeof(int2);
     w.px = (float*)b; b += p * cap * 4 * sizeof(float);
     w.qidx = (int*)b; b += p * cap * sizeof(int);
     w.m = (int*)b; b += p * sizeof(int);
-    w.bound = (unsigned*)b; b += p * sizeof(unsigned);
     w.n_alive = (int*)b; b += p * sizeof(int);
-    w.n_tasks = (int*)b; b += 16;
-    w.task = (int2*)b; b += p * (size_t)((n_hyp + 63) / 64) * sizeof(int2);
-    w.list = (unsigned short*)b;
+    w.n_tasks = (int*)b;
     return w;
 }
 
@@ -430,7 +431,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     double* xn = w.xn + (size_t)pair * a.cap * 4;
     float* px = w.px + (size_t)pair * a.cap * 4;
     int* qidx = w.qidx + (size_t)pair * a.cap;
-    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; w.bound[pair] = 0x7F800000u; if (pair == 0) *w.n_tasks = 0; }
+    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; w.n_alive[pair] = 0; if (pair == 0) *w.n_tasks = 0; }
+    for (int j = tid; j < (a.n_hyp + 63) / 64; j += TV_BLOCK) w.wkey[(size_t)pair * ((a.n_hyp + 63) / 64) + j] = ~0ull;
     __syncthreads();
     if (a.d_p1) {  // explicit correspondences
         int m = a.m_fixed;
@@ -519,20 +521,15 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
         valid = eight_point(pts, E) && (a.model ? project_rank2(E) : project_essential(E));
     }
     if (!valid) for (int j = 0; j < 9; j++) E[j] = 0.0;
-    if (h < a.n_hyp) {
-        double* o = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
-        for (int j = 0; j < 9; j++) o[j] = E[j];
-    }
     // MSAC score: sum of Sampson distances truncated at thr^2 (a pure inlier count prefers slightly perturbed
     // models that catch more chance inliers).  Compared as float32, ties -> lowest hypothesis index.
     // The correspondences are the same for every lane: they arrive through wave-uniform scalar loads (constant address
     // space; k_tv_prep wrote them in an earlier launch) and feed the fp64 FMAs as scalar operands, one per instruction.
     //
-    // Staged scoring (exact): this kernel only sums the first F = tv_first(m) correspondences and stores that partial
-    // cost.  The hypothesis with the smallest partial cost of each block is then scored completely by the whole block;
-    // its total (rounded up) is an upper bound of the best total of the pair.  A hypothesis whose PARTIAL cost already
-    // exceeds the bound cannot win (costs only grow), so k_tv_score finishes only the others -- typically 5-20 % --
-    // packed densely into wavefronts.
+    // Staged scoring (exact): every hypothesis first sums the first F = tv_first(m) correspondences.  The hypothesis with
+    // the smallest partial cost of the block is then scored completely by the whole block; its total (rounded up) is an
+    // upper bound of the best total of the pair.  A hypothesis whose PARTIAL cost already exceeds the bound cannot win
+    // (costs only grow), so only the others -- typically 5-20 % -- are finished, compacted into the first wavefronts.
     typedef const __attribute__((address_space(4))) double* cdp;
     const cdp pts = (cdp)(uintptr_t)xn;
     const int F = staged ? tv_first(m) : m;
@@ -544,89 +541,105 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
             cost += fmin(err, thr2);
         }
     }
+    const int lane = tid & 63, wv = tid >> 6;
+    const size_t ntask_max = (size_t)((a.n_hyp + 63) / 64);
     unsigned long long key = ~0ull;
     if (valid && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
-    if (staged && h < a.n_hyp) w.part[(size_t)pair * a.n_hyp + h] = key != ~0ull ? cost : __longlong_as_double(0x7FF0000000000000ll);
     const unsigned long long own = key;
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long other = __shfl_xor(key, o, 64);
         key = other < key ? other : key;
     }
-    if ((tid & 63) == 0) s_best[tid >> 6] = key;
+    if (lane == 0) s_best[wv] = key;
     __syncthreads();
     for (int k = 0; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;  // block minimum, in every thread
-    if (!staged) {
-        if (tid == 0 && key != ~0ull) atomicMin(&w.best[pair], key);
+    if (key == ~0ull) return;  // no valid hypothesis in this block (block-uniform)
+    __shared__ double s_cand[10];
+    if (!staged) {  // every cost is already complete: the block's best goes straight to the pair's minimum
+        if (own == key) {  // (a block index is a valid slot: there are at least as many 64-tasks as 256-blocks)
+            double* bE = w.wE + ((size_t)pair * ntask_max + blockIdx.x) * 9;
+            for (int j = 0; j < 9; j++) bE[j] = E[j];
+            w.wkey[(size_t)pair * ntask_max + blockIdx.x] = key;
+            atomicMin(&w.best[pair], key);
+        }
         return;
     }
-    if (key == ~0ull) return;  // no valid hypothesis in this block (block-uniform)
     // the block's candidate: total cost by all threads -> bound
-    __shared__ double s_cand[10];
     __shared__ double s_sum[TV_BLOCK / 64];
+    __shared__ unsigned s_bound;
     if (own == key) {
         for (int j = 0; j < 9; j++) s_cand[j] = E[j];
         s_cand[9] = cost;
     }
     __syncthreads();
-    double Ec[9];
-    for (int j = 0; j < 9; j++) Ec[j] = s_cand[j];
-    double rest = 0.0;
-    for (int i = F + tid; i < m; i += TV_BLOCK)
-        rest += fmin(sampson_fast(Ec, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]), thr2);
-    for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o, 64);
-    if ((tid & 63) == 0) s_sum[tid >> 6] = rest;
+    {
+        double Ec[9];
+        for (int j = 0; j < 9; j++) Ec[j] = s_cand[j];
+        double rest = 0.0;
+        for (int i = F + tid; i < m; i += TV_BLOCK)
+            rest += fmin(sampson_fast(Ec, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]), thr2);
+        for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o, 64);
+        if (lane == 0) s_sum[wv] = rest;
+    }
     __syncthreads();
     if (tid == 0) {
         double total = s_cand[9];
         for (int k = 0; k < TV_BLOCK / 64; k++) total += s_sum[k];
         // this sum is associated differently from the canonical (sequential) one: two float32 ulps upwards cover that
         // and the rounding to float32, so the bound never undercuts the candidate's canonical cost
-        atomicMin(&w.bound[pair], __float_as_uint((float)total) + 2u);
+        s_bound = __float_as_uint((float)total) + 2u;
+    }
+    __syncthreads();
+    // survivors (float32(partial cost) <= bound; costs are >= 0, so bit order = value order) -> the pair's dense list in
+    // HBM (order is irrelevant for a minimum; the candidate itself always survives): one atomic per block
+    __shared__ int s_wcnt[TV_BLOCK / 64];
+    __shared__ int s_gbase;
+    const bool alive = own != ~0ull && __float_as_uint((float)cost) <= s_bound;
+    const unsigned long long mk = __ballot(alive);
+    if (lane == 0) s_wcnt[wv] = __popcll(mk);
+    __syncthreads();
+    int sbase = 0, n_alive = 0;
+    for (int k = 0; k < TV_BLOCK / 64; k++) { if (k < wv) sbase += s_wcnt[k]; n_alive += s_wcnt[k]; }
+    if (tid == 0) s_gbase = atomicAdd(&w.n_alive[pair], n_alive);
+    __syncthreads();
+    if (alive) {
+        double* rec = w.surv + ((size_t)pair * a.n_hyp + s_gbase + sbase + __popcll(mk & ((1ull << lane) - 1ull))) * TV_REC;
+        for (int j = 0; j < 9; j++) rec[j] = E[j];
+        rec[9] = cost;
+        rec[10] = __longlong_as_double((long long)h);
     }
 }
 
-// Second stage of the staged scoring.  k_tv_compact lists the survivors of a pair (float32(partial cost) <= bound; the
-// order is irrelevant for a minimum); k_tv_score gives every 64 of them one wavefront, which continues each survivor's
-// sequential sum over the remaining correspondences: bit-identical to an unstaged sum.
-__global__ __launch_bounds__(TV_BLOCK) void k_tv_compact(TwoViewArgs a, TvWork w) {
-    __shared__ int s_cnt;
-    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    const int m = w.m[pair];
-    if (m >= 8) {
-        const unsigned bound = w.bound[pair];
-        const double* part = w.part + (size_t)pair * a.n_hyp;
-        unsigned short* list = w.list + (size_t)pair * a.n_hyp;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int h0 = 0; h0 < a.n_hyp; h0 += TV_BLOCK) {  // block-uniform trip count
-            const int h = h0 + tid;
-            const bool alive = h < a.n_hyp && __float_as_uint((float)part[h]) <= bound;  // costs are >= 0: bit order = value order
-            const unsigned long long mk = __ballot(alive);
-            int base = 0;
-            if (lane == 0 && mk) base = atomicAdd(&s_cnt, __popcll(mk));
-            base = __shfl(base, 0, 64);
-            if (alive) list[base + __popcll(mk & lt)] = (unsigned short)h;
+// One task per 64 survivors of a pair, appended to a launch-wide dense table: k_tv_score's workgroup t takes task t, so the busy
+// wavefronts are the FIRST ones of its grid and spread evenly over the chip (the empty tail exits at once).
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_tasks(TwoViewArgs a, TvWork w) {
+    __shared__ int s_off[TV_BLOCK + 1];
+    const int tid = threadIdx.x;
+    int total = 0;
+    for (int p0 = 0; p0 < a.n_pairs; p0 += TV_BLOCK) {  // block-uniform trip count
+        const int p = p0 + tid;
+        const int nt = p < a.n_pairs ? (w.n_alive[p] + 63) / 64 : 0;
+        s_off[tid + 1] = nt;
+        __syncthreads();
+        if (tid == 0) {
+            s_off[0] = total;
+            for (int k = 0; k < TV_BLOCK; k++) s_off[k + 1] += s_off[k];
         }
+        __syncthreads();
+        for (int j = 0; j < nt; j++) w.task[s_off[tid] + j] = make_int2(p, j);
+        total = s_off[TV_BLOCK];
+        __syncthreads();
     }
-    __syncthreads();
-    // one task per 64 survivors, appended to a launch-wide dense table: k_tv_score's workgroup t takes task t, so the busy
-    // wavefronts are the FIRST ones of its grid and spread evenly over the chip (the empty tail exits at once)
-    __shared__ int s_tbase;
-    const int ntask = (s_cnt + 63) / 64;
-    if (tid == 0) {
-        w.n_alive[pair] = s_cnt;
-        s_tbase = ntask ? atomicAdd(w.n_tasks, ntask) : 0;
-    }
-    __syncthreads();
-    for (int j = tid; j < ntask; j += TV_BLOCK) w.task[s_tbase + j] = make_int2(pair, j * 64);
+    if (tid == 0) *w.n_tasks = total;
 }
 
+// Second stage: every lane continues one survivor's sequential sum over the remaining correspondences (bit-identical to an
+// unstaged sum); the wavefront's best goes to the pair's minimum and, with its matrix, to the slot k_tv_finish looks it up in.
 __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= *w.n_tasks) return;
     const int2 tk = w.task[blockIdx.x];
-    const int pair = tk.x, t0 = tk.y;
+    const int pair = tk.x, t0 = tk.y * 64;
     const int total = w.n_alive[pair];
     const int m = w.m[pair];
     const double thr = tv_thr(a, w, pair);
@@ -636,23 +649,29 @@ __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
     const cdp pts = (cdp)(uintptr_t)xn;
     const int F = tv_first(m);
     const bool on = t0 + lane < total;
-    const int h = w.list[(size_t)pair * a.n_hyp + (on ? t0 + lane : t0)];
-    const double* Eg = w.hypE + ((size_t)pair * a.n_hyp + h) * 9;
+    const double* rec = w.surv + ((size_t)pair * a.n_hyp + (on ? t0 + lane : t0)) * TV_REC;
     double E[9];
-    for (int j = 0; j < 9; j++) E[j] = Eg[j];
-    double cost = w.part[(size_t)pair * a.n_hyp + h];
+    for (int j = 0; j < 9; j++) E[j] = rec[j];
+    double cost = rec[9];
+    const unsigned h = (unsigned)__double_as_longlong(rec[10]);
 #pragma unroll 4
     for (int i = F; i < m; i++) {
         double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
         cost += fmin(err, thr2);
     }
     unsigned long long key = ~0ull;
-    if (on && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
+    if (on && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)h;
+    const unsigned long long own = key;
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long other = __shfl_xor(key, o, 64);
         key = other < key ? other : key;
     }
-    if (lane == 0 && key != ~0ull) atomicMin(&w.best[pair], key);
+    if (key != ~0ull && own == key) {  // exactly one lane (keys are unique)
+        const size_t slot = (size_t)pair * ((a.n_hyp + 63) / 64) + tk.y;
+        for (int j = 0; j < 9; j++) w.wE[slot * 9 + j] = E[j];
+        w.wkey[slot] = key;
+        atomicMin(&w.best[pair], key);
+    }
 }
 
 // ---------------------------------------------------------------- finish --------------------------
@@ -726,13 +745,19 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
         }
         return;
     }
-    const int hbest = (int)(unsigned)(best & 0xFFFFFFFFull);
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
     const float* px = w.px + (size_t)pair * a.cap * 4;
     const int* qidx = w.qidx + (size_t)pair * a.cap;
     const double thr = tv_thr(a, w, pair);
     const double thr2 = thr * thr;
-    if (tid < 9) s_E[tid] = given ? a.d_E_in[(size_t)pair * 9 + tid] : w.hypE[((size_t)pair * a.n_hyp + hbest) * 9 + tid];
+    if (given) {
+        if (tid < 9) s_E[tid] = a.d_E_in[(size_t)pair * 9 + tid];
+    } else {  // the matrix of the winning key: every scoring wavefront (or unstaged block) left its best in a slot of the pair
+        const int nslot = (a.n_hyp + 63) / 64;
+        for (int j = tid; j < nslot; j += TVF_BLOCK)
+            if (w.wkey[(size_t)pair * nslot + j] == best)
+                for (int q = 0; q < 9; q++) s_E[q] = w.wE[((size_t)pair * nslot + j) * 9 + q];
+    }
     __syncthreads();
 
     // ---- local optimisation: least-squares 8-point refits (9x9 normal matrix, 45 unique sums, Jacobi) on an
@@ -1010,10 +1035,10 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
         HIPCHK(c, hipGetLastError());
         return MO_OK;
     }
-    const int staged = a.n_hyp >= 512 && a.n_hyp <= 65536;  // the survivor list is u16
+    const int staged = a.n_hyp >= 512;  // below that the bound of one or two blocks prunes too little to pay for the second stage
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged);
     if (staged) {
-        hipLaunchKernelGGL(k_tv_compact, dim3(a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w);
+        hipLaunchKernelGGL(k_tv_tasks, dim3(1), dim3(TV_BLOCK), 0, c->stream, a, w);
         hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64), 0, c->stream, a, w);
     }
     hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
