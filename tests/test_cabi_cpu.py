@@ -67,3 +67,27 @@ def test_initializer_guards():
     assert P.shape == (3, 4) and np.allclose(P[:, 3], [2, 4, 3])
     X = convert_to_3d_points(np.array([[2.0, 4], [4, 8], [6, 12], [2, 4]], np.float32))
     assert np.allclose(X, [[1, 2, 3], [1, 2, 3]])
+
+
+def test_option_b_shadowing(tmp_path):
+    """INTEGRATION.md Option B: with <repo>/visual-slam_amd ahead of the reference's src on sys.path, a tracker module living in the
+    REFERENCE's orbslam2 directory resolves its relative imports (tracker.py:9-11) to this repo's modules.  The reference tree is
+    imitated by a stand-in with the same shape (no __init__.py, a tracker with the three relative imports, and decoy modules that
+    must lose)."""
+    import subprocess
+    import sys
+    ref = tmp_path / "src" / "orbslam2"
+    ref.mkdir(parents=True)
+    (ref / "__init.py__").write_text("")  # the reference's misnamed init file: the directory is a namespace portion
+    for name in ("extractor", "matcher", "initializer", "utils"):
+        (ref / (name + ".py")).write_text("DECOY = True\nclass ORBExtractor: pass\nclass DescriptorMatcher: pass\nclass MapInitializer: pass\n")
+    (ref / "tracker.py").write_text("from .extractor import ORBExtractor\nfrom .matcher import DescriptorMatcher\n"
+                                    "from .initializer import MapInitializer\nfrom .utils import compute_projection_matrix\n")
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import orbslam2.tracker as t, orbslam2.extractor as e\n"
+            "assert t.__file__.startswith(%r), t.__file__\n"
+            "assert not hasattr(e, 'DECOY') and 'visual-slam_amd' in e.__file__, e.__file__\n"
+            "assert t.ORBExtractor is e.ORBExtractor and 'visual-slam_amd' in sys.modules[t.DescriptorMatcher.__module__].__file__\n"
+            "print('ok')" % (os.path.join(ROOT, "visual-slam_amd"), str(tmp_path / "src"), str(ref)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
