@@ -5,12 +5,14 @@
 //   gray      BGR -> Y, fixed-point 15-bit                                   (only for 3-channel input)
 //   resize    level L from level L-1, INTER_LINEAR_EXACT fixed point          (nlevels-1 dependent launches)
 //   fast      FAST-9/16 score + 3x3 NMS + border filter, full-width strips,   raster-ordered candidate slots
-//             pixel tiles and the score band staged in LDS
+//             pixel tiles and the score band staged in LDS; compass pre-test -> polarity stacks -> one-sided 16-bit score
+//             of the survivors -> NMS on the listed corners -> bitmap -> ordered compaction
 //   select    per (frame, level): retainBest(2q) on FAST score -> Harris -> retainBest(q), exact
 //             standard-library permutation replay (select_replay.h), record arrays in LDS
 //   blur      7x7 Gaussian, 8-bit quantised taps, separable in LDS, REFLECT_101
-//   describe  one wavefront per keypoint: intensity-centroid angle (rows on lanes, DPP-style wave reduce)
-//             + 256 rotated rBRIEF tests (4 per lane)
+//   describe  a quarter wavefront (16 lanes) per keypoint: both windows fetched into registers up front, a group-private
+//             LDS patch, intensity-centroid angle (2 disc rows per lane + 16-lane reduction), 256 rotated rBRIEF tests
+//             (16 per lane); compute() with caller keypoints: one wavefront per keypoint, 4 tests per lane
 // All arithmetic is integer or non-contracted float32 (compile with -ffp-contract=off) so results are
 // bit-identical to the CPU oracle.
 #include <cstring>
@@ -52,8 +54,8 @@ int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, ui
 
 // ------------------------------------------------------------------ resize --------------------------
 #define RS_TW 64
-#define RS_TH 32
-#define RS_SRC_ROWS 72    // source rows a 32-row output tile can touch (scale <= 2) + 1
+#define RS_TH 64
+#define RS_SRC_ROWS 136   // source rows a 64-row output tile can touch (scale <= 2) + 1
 #define RS_SRC_PITCH 144  // source columns a 64-column output tile can touch (scale <= 2) + alignment lead-in
 
 // INTER_LINEAR_EXACT level L from level L-1: one workgroup = 64x32 output tile.  The source window is staged in LDS
@@ -158,8 +160,11 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels)
 
 // ------------------------------------------------------------------ blur ----------------------------
 #define BT_W 64
-#define BT_H 26   // output rows per tile: 26 + 6 halo rows = 16 row pairs
-#define BT_PW 80  // LDS pixel-tile pitch: 4 (aligned lead-in) + 64 + 3 halo, rounded to a multiple of 16
+#define BT_QW (BT_W / 4)      // quads (4 adjacent outputs) per tile row
+#define BT_PP (256 / BT_QW)   // row pairs one pass of the workgroup covers
+#define BT_H 58   // output rows per tile: 58 + 6 halo rows = 32 row pairs, two passes of 16 (round 1: 26 rows; half the workgroups,
+                  // 10 % instead of 23 % halo rows)
+#define BT_PW (BT_W + 16)  // LDS pixel-tile pitch: 4 (aligned lead-in) + BT_W + 3 halo, rounded to a multiple of 16
 #define BT_ROWS (BT_H + 6)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -192,12 +197,12 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
     const int tx0 = (int)((te >> 8) & 0xFFF) * BT_W, ty0 = (int)(te >> 20) * BT_H;
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int tid = threadIdx.x;
-    // s_px column c holds level column tx0 - 4 + c  (c = 1 .. 70 are used).  Rows are reflected per tile row
+    // s_px column c holds level column tx0 - 4 + c  (c = 1 .. BT_W + 6 are used).  Rows are reflected per tile row
     // (REFLECT_101); a dword whose four columns lie inside the level is one aligned load, the few that touch the left or
     // right border are assembled from reflected bytes -- border tiles cost about the same as interior ones.
     if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {
-        for (int i = tid; i < BT_ROWS * 18; i += 256) {
-            const int r = i / 18, c4 = i - r * 18;
+        for (int i = tid; i < BT_ROWS * (BT_QW + 2); i += 256) {
+            const int r = i / (BT_QW + 2), c4 = i - r * (BT_QW + 2);
             const int y = reflect101(ty0 + r - 3, lv.h), x0 = tx0 - 4 + 4 * c4;
             const uint8_t* row = img + (size_t)y * lv.pitch;
             uint32_t v;
@@ -218,9 +223,10 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
     }
     __syncthreads();
     const uint32_t g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];
-    {   // row pass: one task = 4 adjacent outputs of tile rows 2p and 2p+1 (16 row pairs x 16 quads = 256 tasks)
+#pragma unroll
+    for (int h2 = 0; h2 < BT_ROWS / 2 / BT_PP; h2++) {   // row pass: one task = 4 adjacent outputs of tile rows 2p and 2p+1 (BT_PP row pairs x BT_QW quads per pass)
         const uint32_t ta = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), tb = g2 | (g1 << 8) | (g0 << 16);
-        const int p = tid >> 4, q = tid & 15;
+        const int p = tid / BT_QW + BT_PP * h2, q = tid % BT_QW;
         uint32_t o[2][4];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -240,8 +246,9 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
         *(uint4*)(&s_row[p * BT_W + 4 * q]) = packed;
     }
     __syncthreads();
-    {   // column pass: each thread 4 adjacent columns of output rows 2p and 2p+1, from row pairs p .. p+3
-        const int p = tid >> 4, c0 = (tid & 15) * 4;
+#pragma unroll
+    for (int h2 = 0; h2 < BT_ROWS / 2 / BT_PP; h2++) {   // column pass: each thread 4 adjacent columns of output rows 2p and 2p+1, from row pairs p .. p+3
+        const int p = tid / BT_QW + BT_PP * h2, c0 = (tid % BT_QW) * 4;
         const int x = tx0 + c0, y = ty0 + 2 * p;
         if (p < BT_H / 2 && y < lv.h && x < lv.w) {
             // even output row 2p   : rows 2p .. 2p+6   = pairs (g0,g1) (g2,g3) (g2,g1) (g0, 0)
@@ -985,7 +992,8 @@ __device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch,
 // issued up front into registers, the raw window is stored and reduced to the angle while the blurred one is still in
 // flight, then the blurred window takes its place.  A patch is only touched by the 16 lanes of its group, which sit in
 // one wavefront and execute in lockstep, so no barrier is needed.  1716 B of LDS per keypoint (27 KB per workgroup,
-// 5 workgroups per CU) is what sets the speed: the kernel is bound by load latency x occupancy.
+// 5 workgroups per CU).  Measured bound: vector issue (~1300 instructions per wavefront) with the LDS 75 % busy;
+// ablating any one phase (angle loop, sincos, the 256 tests) moves the kernel by 2-7 % only.
 template <bool HAS_DESC>  // compile-time: a run-time branch around the blurred loads would hide their count from s_waitcnt
 __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                   const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
