@@ -358,12 +358,21 @@ __device__ __forceinline__ unsigned long long ballot_gt16(int a, int b) {
     return m;
 }
 
+// ds_write_b16 of val at LDS byte address addr by exactly the lanes of mask (a wave mask the caller already holds in scalar
+// registers): EXEC is narrowed to the mask around the store instead of rebuilding a per-lane predicate from it (two v_and, a
+// 64-bit compare and a branch per push otherwise).  A store with EXEC = 0 is a no-op.
+__device__ __forceinline__ void lds_store_u16_masked(unsigned long long mask, uint32_t addr, uint32_t val) {
+    unsigned long long keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(keep) : "s"(mask), "v"(addr), "v"(val) : "memory", "scc");
+}
+
 #define FAST_CORNER_CAP 896   // listed corners per strip (typical: 300); more -> dense fallback
 #define FAST_KEEP_WORDS 512   // strip_rows * bw <= 16384 candidate positions (mo_build_plan)
 #define FAST_STACK 384        // u16 entries per wavefront: two stacks of <= 191
 
-template <int TW>  // LDS tile pitch: a compile-time constant so the 16 circle reads use immediate offsets
-__global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict__ strip_tab, uint32_t inv_per,
+template <int TW, int NT>  // TW: LDS tile pitch, a compile-time constant so the 16 circle reads use immediate offsets; NT: threads
+__global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict__ strip_tab, uint32_t inv_per,
                                               const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -386,15 +395,16 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
     const int xs0 = lv.bx0 - 1;
     uint8_t* s_score = smem;            // (R+2) rows x SW
     uint8_t* s_tile = smem + score_bytes;
-    __shared__ int s_wsum[4];
+    constexpr int NW = NT / 64;
+    __shared__ int s_wsum[NW];
     // per-wavefront stacks of the pixels that pass the compass pre-test (row << 12 | column): the darker-arc candidates grow
     // up from [0], the brighter-arc candidates down from [FAST_STACK - 1]; each holds <= 63 + 128 entries
-    __shared__ __attribute__((aligned(16))) uint16_t s_wq[4][FAST_STACK];
+    __shared__ __attribute__((aligned(16))) uint16_t s_wq[NW][FAST_STACK];
     __shared__ uint16_t s_corner[FAST_CORNER_CAP];  // band positions (row * SW + column) of the pixels with a non-zero score
     __shared__ int s_ncorner;
     // bit (rr * bw + xx) set <=> border-region pixel survives the 3x3 NMS; overlays the stacks, which are dead by then
     uint32_t* const s_keep = (uint32_t*)&s_wq[0][0];
-    static_assert(sizeof(uint16_t) * 4 * FAST_STACK >= 4 * FAST_KEEP_WORDS, "bitmap overlays the stacks");
+    static_assert(sizeof(uint16_t) * NW * FAST_STACK >= 4 * FAST_KEEP_WORDS, "bitmap overlays the stacks");
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int t = P.fast_threshold;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -409,25 +419,25 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
     if (al16) {  // 16 bytes per lane; pitch >= the rounded row end because pitch is a multiple of 16
         const int tw16 = (SW + 6 + lead + 15) >> 4;
         const uint32_t inv = 0xFFFFFFFFu / (uint32_t)tw16 + 1u;  // i / tw16 == mulhi(i, inv) while i * tw16 < 2^32
-        for (int i = tid; i < th * tw16; i += 256) {
+        for (int i = tid; i < th * tw16; i += NT) {
             const int r = tw16 > 1 ? (int)__umulhi((uint32_t)i, inv) : i, c16 = i - r * tw16;
             *(uint4*)(s_tile + r * TW + 16 * c16) = *(const uint4*)(img + (size_t)(gy0 + r) * lv.pitch + gx0 + 16 * c16);
         }
     } else if (al4) {
         const int tw4 = (SW + 6 + lead + 3) >> 2;
-        for (int r = wv; r < th; r += 4) {
+        for (int r = wv; r < th; r += NW) {
             const uint32_t* src = (const uint32_t*)(img + (size_t)(gy0 + r) * lv.pitch + gx0);
             uint32_t* dst = (uint32_t*)(s_tile + r * TW);
             for (int c4 = lane; c4 < tw4; c4 += 64) dst[c4] = src[c4];
         }
     } else {
         const int tw_used = (SW + 6 + lead + 3) & ~3;
-        for (int r = wv; r < th; r += 4) {
+        for (int r = wv; r < th; r += NW) {
             const uint8_t* src = img + (size_t)(gy0 + r) * lv.pitch + gx0;
             for (int cc = lane; cc < tw_used; cc += 64) s_tile[r * TW + cc] = (gx0 + cc < lv.w) ? src[cc] : 0;
         }
     }
-    for (int i = tid; i < ((rows + 2) * SW + 3) >> 2; i += 256) ((uint32_t*)s_score)[i] = 0;  // score 0 unless phase 2b says otherwise
+    for (int i = tid; i < ((rows + 2) * SW + 3) >> 2; i += NT) ((uint32_t*)s_score)[i] = 0;  // score 0 unless phase 2b says otherwise
     if (tid == 0) s_ncorner = 0;
     __syncthreads();
 
@@ -443,8 +453,12 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
     //     at 2.3 cycles per wavefront, twice the rate of the packed (v_pk_*) and 32-bit min/max forms.
     typedef const volatile __attribute__((address_space(3))) uint8_t lds_cvu8;  // volatile: byte reads stay separate
     const int t_list = max(t, 1);  // a pixel is listed for phase 3 when its stored score (L - 1 for L > t) is non-zero
-    auto score_one = [&](uint32_t e, int flip, bool own) {  // stack entry = row << 12 | column; own: not a filler lane
-        const int r = e >> 12, x = e & 0xFFF;
+    // stack entry = row << xbits | column: 16-row strips exist only for bw <= 1024 (strip_rows * bw <= 16384), narrower strips
+    // have <= 10 scored rows and bw + 2 <= 4096
+    const int xbits = R > 8 ? 11 : 12;
+    const uint32_t xmask = (1u << xbits) - 1u;
+    auto score_one = [&](uint32_t e, int flip, bool own) {  // own: not a filler lane
+        const int r = e >> xbits, x = e & xmask;
         const int pos = r * SW + x;
         // flip (wave-uniform) = 0xFF: brighter-arc polarity, bytes complemented: (255 - v) - (255 - p) = p - v
         lds_cvu8* p = (lds_cvu8*)&s_tile[(r + 3) * TW + x + 3 + lead];
@@ -481,7 +495,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
         int qd = 0, qb = 0;  // wave-uniform stack fills (darker-arc / brighter-arc candidates)
         // 64-pixel chunks of the scored rows, numbered row-major; each trip takes two of them (chunk c and c + 4).
         // r*, j*, qd, qb are wave-uniform (scalar registers).
-        int ra = 0, ja = wv, rb = 0, jb = wv + 4;
+        int ra = 0, ja = wv, rb = 0, jb = wv + NW;
         while (ja >= nxc) { ja -= nxc; ra++; }
         while (jb >= nxc) { jb -= nxc; rb++; }
         const int tv = t, ntv = -t;
@@ -500,11 +514,11 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
             const int second_lo = min16(min16(max16(mn_a, mn_b), mx_a), mx_b);
             const unsigned long long md = ballot_gt16(second_hi, tv) & valid;   // centre above >= 2 compass pixels by more than t
             const unsigned long long mb = ballot_gt16(ntv, second_lo) & valid;  // centre below >= 2 compass pixels by more than t
-            const uint16_t e = (uint16_t)((r << 12) | x);
-            if ((md >> lane) & 1ull) wq[qd + __builtin_amdgcn_mbcnt_hi((unsigned)(md >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)md, 0u))] = e;
+            const uint32_t e = (uint32_t)((r << xbits) | x);
+            const uint32_t wq_lds = (uint32_t)(uintptr_t)wq;  // LDS byte address of this wavefront's stacks
+            lds_store_u16_masked(md, wq_lds + 2u * (uint32_t)(qd + __builtin_amdgcn_mbcnt_hi((unsigned)(md >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)md, 0u))), e);
             qd += __popcll(md);
-            if ((mb >> lane) & 1ull)
-                wq[FAST_STACK - 1 - qb - __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))] = e;
+            lds_store_u16_masked(mb, wq_lds + 2u * (uint32_t)(FAST_STACK - 1 - qb - (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0u))), e);
             qb += __popcll(mb);
         };
         while (ra < rows + 2) {
@@ -516,9 +530,9 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
                 while (qb >= 64) { qb -= 64; score_one(wq[FAST_STACK - 1 - qb - lane], 0xFF, true); }
                 replay::wave_sync();  // the entries just read may be overwritten by the next pushes
             }
-            ja += 8;
+            ja += 2 * NW;
             while (ja >= nxc) { ja -= nxc; ra++; }
-            jb += 8;
+            jb += 2 * NW;
             while (jb >= nxc) { jb -= nxc; rb++; }
         }
         replay::wave_sync();
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
         if (qb > 0) score_one(wq[FAST_STACK - 1 - min(lane, qb - 1)], 0xFF, lane < qb);
     }
     __syncthreads();
-    for (int i = tid; i < FAST_KEEP_WORDS; i += 256) s_keep[i] = 0;  // the stacks are dead: their space becomes the keep bitmap
+    for (int i = tid; i < FAST_KEEP_WORDS; i += NT) s_keep[i] = 0;  // the stacks are dead: their space becomes the keep bitmap
     __syncthreads();
 
     // ---- 3. NMS + border filter on the listed corners -> bitmap -> raster-ordered compaction
@@ -548,10 +562,10 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
             }
         };
         if (nc <= FAST_CORNER_CAP) {
-            for (int k = tid; k < nc; k += 256) nms_at(s_corner[k]);
+            for (int k = tid; k < nc; k += NT) nms_at(s_corner[k]);
         } else {  // the list overflowed: dense scan of the score band, one dword (4 positions) per lane and trip
             const int nband = (rows + 2) * SW;
-            for (int k = tid; 4 * k < nband; k += 256) {
+            for (int k = tid; 4 * k < nband; k += NT) {
                 uint32_t w = ((const uint32_t*)s_score)[k];
 #pragma unroll
                 for (int bq = 0; bq < 4; bq++)
@@ -560,7 +574,7 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
         }
     }
     __syncthreads();
-    const int nwords = (nitems + 31) >> 5, wpt = (nwords + 255) >> 8;  // wpt <= 2
+    const int nwords = (nitems + 31) >> 5, wpt = (nwords + NT - 1) / NT;  // wpt <= 2
     uint32_t kw[2] = {0u, 0u};
 #pragma unroll
     for (int q = 0; q < 2; q++)
@@ -576,7 +590,8 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
     __syncthreads();
     int base = 0;
     for (int k = 0; k < wv; k++) base += s_wsum[k];
-    const int total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    int total = 0;
+    for (int k = 0; k < NW; k++) total += s_wsum[k];
     int pos = base + incl - cnt;
     uint32_t* out = cand + (size_t)frame * P.cand_stride + lv.cand_off + (size_t)strip * lv.strip_cap;
 #pragma unroll
@@ -595,13 +610,13 @@ __global__ __launch_bounds__(256) void k_fast(Plan P, const uint32_t* __restrict
     if (tid == 0) strip_cnt[(size_t)frame * P.strips_per_frame + lv.strip_base + strip] = min(total, lv.strip_cap);
 }
 
-template <int TW> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, int batch, size_t score_bytes, int max_rows) {
+template <int TW, int NT> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, int batch, size_t score_bytes, int max_rows) {
     const Plan& P = c->plan;
     size_t lds = score_bytes + (size_t)(max_rows + 8) * TW + 16;
     if (lds > 128 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
-    const unsigned bit = TW == 704 ? 1u : TW == 1344 ? 2u : TW == 2112 ? 4u : TW == 608 ? 32u : 8u;
+    const unsigned bit = (TW == 704 ? 1u : TW == 1344 ? 2u : TW == 2112 ? 4u : TW == 608 ? 32u : 8u) << (NT == 512 ? 8 : 0);
     if (!(c->lds_attr_done & bit)) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_fast<TW, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         c->lds_attr_done |= bit;
     }
     if (!c->d_strip_tab) {  // (re)built with the plan: free_plan_buffers drops it
@@ -613,7 +628,7 @@ template <int TW> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, in
         c->n_strip_tab = (int)tab.size();
     }
     const uint32_t per = (uint32_t)P.strips_per_frame, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;
-    hipLaunchKernelGGL(k_fast<TW>, dim3(P.strips_per_frame, batch), dim3(256), lds, c->stream, P, c->d_strip_tab, inv_per, d_gray,
+    hipLaunchKernelGGL((k_fast<TW, NT>), dim3(P.strips_per_frame, batch), dim3(NT), lds, c->stream, P, c->d_strip_tab, inv_per, d_gray,
                        c->d_pyr, c->d_cand, c->d_strip_cnt, (int)score_bytes);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
@@ -630,11 +645,13 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
         max_rows = std::max(max_rows, v.strip_rows);
     }
     if (P.strips_per_frame < 1) return MO_OK;
-    if (tw_need <= 608) return launch_fast_tw<608>(c, d_gray, batch, score_bytes, max_rows);  // 640-wide frames: 8 workgroups per CU
-    if (tw_need <= 704) return launch_fast_tw<704>(c, d_gray, batch, score_bytes, max_rows);
-    if (tw_need <= 1344) return launch_fast_tw<1344>(c, d_gray, batch, score_bytes, max_rows);
-    if (tw_need <= 2112) return launch_fast_tw<2112>(c, d_gray, batch, score_bytes, max_rows);
-    return launch_fast_tw<4160>(c, d_gray, batch, score_bytes, max_rows);
+    // (the kernel is written for any MO_STRIP_ROWS / thread count; 16-row strips with 512-thread workgroups - half the workgroups,
+    // 12 % instead of 25 % ring rows - measured 3 % SLOWER than 8 rows x 256 threads on MI355X: eight wavefronts per barrier)
+    if (tw_need <= 608) return launch_fast_tw<608, 256>(c, d_gray, batch, score_bytes, max_rows);  // 640-wide frames: 8 workgroups per CU
+    if (tw_need <= 704) return launch_fast_tw<704, 256>(c, d_gray, batch, score_bytes, max_rows);
+    if (tw_need <= 1344) return launch_fast_tw<1344, 256>(c, d_gray, batch, score_bytes, max_rows);
+    if (tw_need <= 2112) return launch_fast_tw<2112, 256>(c, d_gray, batch, score_bytes, max_rows);
+    return launch_fast_tw<4160, 256>(c, d_gray, batch, score_bytes, max_rows);
 }
 
 // ------------------------------------------------------------------ select --------------------------
