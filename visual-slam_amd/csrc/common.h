@@ -140,8 +140,8 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch);
 int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray);
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
 int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
-int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch);
-int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch);
+int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
+int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
                         int* d_counts);
 int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc);

@@ -372,7 +372,7 @@ __device__ __forceinline__ void lds_store_u16_masked(unsigned long long mask, ui
 #define FAST_STACK 384        // u16 entries per wavefront: two stacks of <= 191
 
 template <int TW, int NT>  // TW: LDS tile pitch, a compile-time constant so the 16 circle reads use immediate offsets; NT: threads
-__global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict__ strip_tab, uint32_t inv_per,
+__global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict__ strip_tab, uint32_t inv_per, int strip0,
                                               const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
         frame = (int)((lin & 7) + 8 * q);
         strip = (int)(n - q * gridDim.x);
     }
-    const uint32_t se = strip_tab[strip];  // one wave-uniform table read instead of a level search
+    const uint32_t se = strip_tab[strip0 + strip];  // one wave-uniform table read instead of a level search (strip0: first strip of this launch's levels)
     const int L = se & 0xFF;
     const LevelInfo lv = P.lv[L];
     strip = (int)(se >> 8);
@@ -610,7 +610,8 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
     if (tid == 0) strip_cnt[(size_t)frame * P.strips_per_frame + lv.strip_base + strip] = min(total, lv.strip_cap);
 }
 
-template <int TW, int NT> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, int batch, size_t score_bytes, int max_rows) {
+template <int TW, int NT> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_gray, int batch, size_t score_bytes, int max_rows,
+                                                    int strip0, int nstrips) {
     const Plan& P = c->plan;
     size_t lds = score_bytes + (size_t)(max_rows + 8) * TW + 16;
     if (lds > 128 * 1024) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide for the FAST strip kernel");
@@ -627,15 +628,21 @@ template <int TW, int NT> static int launch_fast_tw(mo_ctx* c, const uint8_t* d_
         HIPCHK(c, hipMemcpy(c->d_strip_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->n_strip_tab = (int)tab.size();
     }
-    const uint32_t per = (uint32_t)P.strips_per_frame, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;
-    hipLaunchKernelGGL((k_fast<TW, NT>), dim3(P.strips_per_frame, batch), dim3(NT), lds, c->stream, P, c->d_strip_tab, inv_per, d_gray,
+    const uint32_t per = (uint32_t)nstrips, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;
+    hipLaunchKernelGGL((k_fast<TW, NT>), dim3(nstrips, batch), dim3(NT), lds, c->stream, P, c->d_strip_tab, inv_per, strip0, d_gray,
                        c->d_pyr, c->d_cand, c->d_strip_cnt, (int)score_bytes);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
 
-int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
+// levels [level_lo, level_hi) of every frame (the strip table is level-major: a level range is a strip range)
+int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, int level_hi) {
     const Plan& P = c->plan;
+    level_lo = std::max(level_lo, 0); level_hi = std::min(level_hi, P.nlevels);
+    if (level_lo >= level_hi) return MO_OK;
+    const int strip0 = P.lv[level_lo].strip_base;
+    const int nstrips = (level_hi < P.nlevels ? P.lv[level_hi].strip_base : P.strips_per_frame) - strip0;
+    if (nstrips < 1) return MO_OK;
     size_t score_bytes = 0;
     int tw_need = 0, max_rows = 1;
     for (int L = 0; L < P.nlevels; L++) {
@@ -647,11 +654,11 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch) {
     if (P.strips_per_frame < 1) return MO_OK;
     // (the kernel is written for any MO_STRIP_ROWS / thread count; 16-row strips with 512-thread workgroups - half the workgroups,
     // 12 % instead of 25 % ring rows - measured 3 % SLOWER than 8 rows x 256 threads on MI355X: eight wavefronts per barrier)
-    if (tw_need <= 608) return launch_fast_tw<608, 256>(c, d_gray, batch, score_bytes, max_rows);  // 640-wide frames: 8 workgroups per CU
-    if (tw_need <= 704) return launch_fast_tw<704, 256>(c, d_gray, batch, score_bytes, max_rows);
-    if (tw_need <= 1344) return launch_fast_tw<1344, 256>(c, d_gray, batch, score_bytes, max_rows);
-    if (tw_need <= 2112) return launch_fast_tw<2112, 256>(c, d_gray, batch, score_bytes, max_rows);
-    return launch_fast_tw<4160, 256>(c, d_gray, batch, score_bytes, max_rows);
+    if (tw_need <= 608) return launch_fast_tw<608, 256>(c, d_gray, batch, score_bytes, max_rows, strip0, nstrips);  // 640-wide frames: 8 workgroups per CU
+    if (tw_need <= 704) return launch_fast_tw<704, 256>(c, d_gray, batch, score_bytes, max_rows, strip0, nstrips);
+    if (tw_need <= 1344) return launch_fast_tw<1344, 256>(c, d_gray, batch, score_bytes, max_rows, strip0, nstrips);
+    if (tw_need <= 2112) return launch_fast_tw<2112, 256>(c, d_gray, batch, score_bytes, max_rows, strip0, nstrips);
+    return launch_fast_tw<4160, 256>(c, d_gray, batch, score_bytes, max_rows, strip0, nstrips);
 }
 
 // ------------------------------------------------------------------ select --------------------------
@@ -789,8 +796,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws);
 }
 
-int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
+int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, int level_hi) {
     const Plan& P = c->plan;
+    level_lo = std::max(level_lo, 0); level_hi = std::min(level_hi, P.nlevels);
+    if (level_lo >= level_hi) return MO_OK;
     for (int L = 0; L < P.nlevels; L++)
         if (P.lv[L].nstrips > SEL_MAXSTRIPS) return mo_fail(c, MO_ERR_UNSUPPORTED, "too many strips per level");
     if (!(c->lds_attr_done & 16u)) {
@@ -800,9 +809,12 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch) {
     // One launch, every workgroup with the full LDS record window (4 resident per CU), levels in dispatch order from fine to
     // coarse: the replays are latency-bound single wavefronts whose length grows with the candidate count, so the long
     // level-0 tasks start first and the short coarse-level tasks fill the slots that free up (longest-task-first packing).
-    // A level that outgrows the window falls back to its HBM scratch slot (same code, slower).
-    hipLaunchKernelGGL(k_select, dim3(batch, P.nlevels), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
-                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags, 0, SEL_BUF_BYTES);
+    // A level that outgrows the window falls back to its HBM scratch slot (same code, slower).  Round 2 re-measured the
+    // alternatives on MI355X: a second launch for the coarse levels with a smaller window (8 - 24 KB, more workgroups per CU):
+    // 0.23 - 0.25 ms against 0.20 ms; selecting the finest level on the auxiliary stream beside FAST of the others: no gain
+    // (the coarse levels alone take 0.19 ms: the kernel is bound by the sum of the replays, not by the finest level).
+    hipLaunchKernelGGL(k_select, dim3(batch, level_hi - level_lo), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags, level_lo, SEL_BUF_BYTES);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
