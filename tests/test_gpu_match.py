@@ -87,3 +87,17 @@ def test_property_random_shapes_and_ties(ctx):
         _check(ctx, q, t, ratio)
 
     run()
+
+
+@pytest.mark.parametrize("nq,nt", [(700, 1000), (100, 4097), (513, 129), (16000, 300), (17000, 300)])
+def test_sliced_train_set_ties(ctx, nq, nt):
+    """Few workgroups -> the default kernel slices the train tiles over gridDim.z and merges per-slice keys (match_launch_pairs);
+    a pool of 5 distinct descriptors puts exact distance ties in every slice, so the merged (idx, dist) must still be the
+    lowest-index ones.  16000 queries is the last size that slices (32 workgroups), 17000 the first that does not."""
+    rng = np.random.default_rng(nq + nt)
+    words = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    q = words[rng.integers(0, 5, nq)].copy()
+    t = words[rng.integers(0, 5, nt)].copy()
+    q[::3, 7] ^= 4
+    _check(ctx, q, t, 0.75)
+    _check(ctx, rng.integers(0, 256, (nq, 32), dtype=np.uint8), rng.integers(0, 256, (nt, 32), dtype=np.uint8), None)

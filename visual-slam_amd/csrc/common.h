@@ -95,6 +95,7 @@ struct mo_ctx {
     // matcher staging
     uint8_t* d_mq = nullptr; uint8_t* d_mt = nullptr; int32_t* d_midx = nullptr; int32_t* d_mdist = nullptr;
     uint8_t* d_mpass = nullptr; size_t m_q_bytes = 0, m_t_bytes = 0, m_n = 0;
+    uint2* d_match_part = nullptr; size_t match_part_bytes = 0;  // per-slice keys of a split k_match_lds launch
     // two-view work buffers
     void* d_tv = nullptr; size_t tv_bytes = 0;
     // generic temp

@@ -7,6 +7,7 @@
 // the inner loop is 8 x (v_xor_b32 + v_bcnt_u32_b32) + a packed (distance << 20 | trainIdx) key folded
 // into the running best / second-best with v_med3_u32 + v_min_u32.  Smallest key == smallest distance,
 // ties towards the lower trainIdx, exactly batch_distance.cpp's strict '<' insertion order.
+#include <algorithm>
 #include <climits>
 
 #include "common.h"
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict_
 #define ML_THREADS 256
 #define ML_Q 2
 #define ML_PER_BLOCK (ML_THREADS * ML_Q)
+#define ML_SPLIT_BLOCKS 32  // launches with at most this many workgroups slice the train set ...
+#define ML_SPLIT_MAX 32     // ... into at most this many slices
 #define ML_TILE 128  // train descriptors per tile: 256 threads x 16 B
 
 __global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restrict__ qbase, const uint8_t* __restrict__ tbase,
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restr
                                                           const int32_t* __restrict__ qf, const int32_t* __restrict__ tf,
                                                           int nq_fixed, int nt_fixed, int out_stride, double ratio,
                                                           int32_t* __restrict__ oidx, int32_t* __restrict__ odist,
-                                                          uint8_t* __restrict__ opass) {
+                                                          uint8_t* __restrict__ opass, uint2* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) uint4 s_t[2][ML_TILE * 2 + 4];  // + one look-ahead group past the last descriptor
     const int pair = blockIdx.y, tid = threadIdx.x;
     const int qfr = qf ? qf[pair] : pair, tfr = tf ? tf[pair] : pair;
@@ -137,9 +140,15 @@ __global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restr
         a[m][4] = hi.x; a[m][5] = hi.y; a[m][6] = hi.z; a[m][7] = hi.w;
         k0[m] = KEY_NONE; k1[m] = KEY_NONE;
     }
-    const int ntile = (nt + ML_TILE - 1) / ML_TILE;
+    // gridDim.z > 1 (few pairs, see match_launch_pairs): this workgroup folds only its slice of the train tiles and leaves its
+    // two best keys in `part`; k_match_merge folds the slices - keys carry the global train index, so the result is the same
+    const int ntile_all = (nt + ML_TILE - 1) / ML_TILE, per_z = (ntile_all + gridDim.z - 1) / gridDim.z;
+    const int tile_lo = blockIdx.z * per_z, ntile = min(ntile_all, tile_lo + per_z);
     const int n16 = nt * 2;  // 16-byte pieces of the train set
-    if (ntile > 0) s_t[0][tid] = tid < n16 ? t[tid] : make_uint4(0, 0, 0, 0);
+    if (tile_lo < ntile) {
+        const int i = tile_lo * ML_TILE * 2 + tid;
+        s_t[tile_lo & 1][tid] = i < n16 ? t[i] : make_uint4(0, 0, 0, 0);
+    }
     // the query registers are complete HERE: otherwise their vmcnt wait lands inside the tile loop and, counting in issue
     // order, would also wait for the next tile's prefetch on every trip
 #pragma unroll
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restr
 #pragma unroll
         for (int k = 0; k < 8; k++) asm volatile("" : "+v"(a[m][k]));
     __syncthreads();
-    for (int tile = 0; tile < ntile; tile++) {
+    for (int tile = tile_lo; tile < ntile; tile++) {
         const bool more = tile + 1 < ntile;
         uint4 nxt = make_uint4(0, 0, 0, 0);
         if (more) {
@@ -190,8 +199,26 @@ __global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restr
 #pragma unroll
     for (int m = 0; m < ML_Q; m++) {
         const int qi = blockIdx.x * ML_PER_BLOCK + m * ML_THREADS + tid;
-        if (qi < nq) emit_match_key(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
+        if (qi < nq && part) part[((size_t)pair * gridDim.z + blockIdx.z) * out_stride + qi] = make_uint2(k0[m], k1[m]);
+        if (qi < nq && !part) emit_match_key(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
     }
+}
+
+// Folds the per-slice key pairs of a split k_match_lds launch (one thread per query).
+__global__ __launch_bounds__(256) void k_match_merge(const uint2* __restrict__ part, int n_split, const int32_t* __restrict__ counts,
+                                                     const int32_t* __restrict__ qf, int nq_fixed, int out_stride, double ratio,
+                                                     int32_t* __restrict__ oidx, int32_t* __restrict__ odist,
+                                                     uint8_t* __restrict__ opass) {
+    const int pair = blockIdx.y, qi = blockIdx.x * 256 + threadIdx.x;
+    const int nq = counts ? min(counts[qf ? qf[pair] : pair], out_stride) : nq_fixed;
+    if (qi >= nq) return;
+    uint32_t k0 = KEY_NONE, k1 = KEY_NONE;
+    for (int z = 0; z < n_split; z++) {
+        const uint2 k = part[((size_t)pair * n_split + z) * out_stride + qi];
+        k1 = med3_u32(k0, k1, k.x); k0 = min(k0, k.x);
+        k1 = med3_u32(k0, k1, k.y); k0 = min(k0, k.y);
+    }
+    emit_match_key(k0, k1, ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -361,8 +388,25 @@ int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t
     const bool al16 = ((((size_t)d_q) | ((size_t)d_t) | q_stride | t_stride) & 15) == 0;
     if (c->match_mode != 2 && al16) {  // default: LDS-staged train tiles
         dim3 grid((nq_max + ML_PER_BLOCK - 1) / ML_PER_BLOCK, n_pairs);
+        // a handful of workgroups (the single-pair calls of the host API) would leave most of the 256 CUs idle: slice the train
+        // tiles over gridDim.z and merge the per-slice keys
+        const int ntile = (nt_max + ML_TILE - 1) / ML_TILE, blocks = (int)grid.x * n_pairs;
+        const int n_split = blocks <= ML_SPLIT_BLOCKS ? std::min(std::min(ntile, ML_SPLIT_MAX), 256 / blocks) : 1;
+        if (n_split > 1) {
+            const size_t need = (size_t)n_pairs * n_split * out_stride * sizeof(uint2);
+            if (int rc = mo_reserve(c, c->d_match_part, c->match_part_bytes, need)) return rc;
+            grid.z = n_split;
+            hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf,
+                               d_tf, nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass, c->d_match_part);
+            HIPCHK(c, hipGetLastError());
+            hipLaunchKernelGGL(k_match_merge, dim3((nq_max + 255) / 256, n_pairs), dim3(256), 0, c->stream,
+                               c->d_match_part, n_split, d_counts, d_qf, nq_fixed, out_stride, ratio, d_idx, d_dist,
+                               d_pass);
+            HIPCHK(c, hipGetLastError());
+            return MO_OK;
+        }
         hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf, d_tf,
-                           nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
+                           nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass, (uint2*)nullptr);
         HIPCHK(c, hipGetLastError());
         return MO_OK;
     }
