@@ -98,9 +98,13 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     }
     if ((spitch & 3) == 0 && (((size_t)s) & 3) == 0) {
         const int ndw = (ncols + 3) >> 2;
+        // i / ndw by a 20-bit reciprocal: exact while i * ndw < 2^20 (i < 136 * 36); a generic integer division per dword was
+        // two thirds of this kernel's vector instructions
+        const uint32_t inv = 0x100000u / (uint32_t)ndw + 1u;
+        const uint8_t* s0 = s + (size_t)sy0 * spitch + sxa;
         for (int i = tid; i < nrows * ndw; i += 256) {
-            int r = i / ndw, c4 = i - r * ndw;
-            ((uint32_t*)(s_src + r * RS_SRC_PITCH))[c4] = *(const uint32_t*)(s + (size_t)(sy0 + r) * spitch + sxa + 4 * c4);
+            const uint32_t r = ((uint32_t)i * inv) >> 20, c4 = (uint32_t)i - r * (uint32_t)ndw;
+            ((uint32_t*)(s_src + r * RS_SRC_PITCH))[c4] = *(const uint32_t*)(s0 + r * (uint32_t)spitch + 4u * c4);
         }
     } else {
         for (int i = tid; i < nrows * ncols; i += 256) {
@@ -172,6 +176,14 @@ __device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
 }
 
+// {sat_u8(a >> 16), sat_u8(b >> 16)} in bits 0-7 and 8-15 (a, b < 2^31): five slow-class instructions pack four outputs instead
+// of a shift, a min and a shift-or each
+__device__ __forceinline__ uint32_t hi16_pair_sat_u8(uint32_t a, uint32_t b) {
+    uint32_t d;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(__builtin_amdgcn_perm(b, a, 0x07060302u)));
+    return d;
+}
+
 // 7x7 Gaussian (8-bit quantised taps, sum 257), separable through LDS: u8 tile -> u16 row sums -> u8 output, all in
 // integer dot instructions.  Row pass: the 7 taps of one output are two v_dot4_u32_u8 on byte windows cut out of three
 // aligned dwords with v_alignbyte.  The u16 row sums of tile rows 2p and 2p+1 are stored interleaved in one dword per
@@ -201,10 +213,11 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
     // (REFLECT_101); a dword whose four columns lie inside the level is one aligned load, the few that touch the left or
     // right border are assembled from reflected bytes -- border tiles cost about the same as interior ones.
     if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {
-        for (int i = tid; i < BT_ROWS * (BT_QW + 2); i += 256) {
-            const int r = i / (BT_QW + 2), c4 = i - r * (BT_QW + 2);
+        // BT_QW interior dwords per row by BT_PP rows per pass, then the two halo dwords of every row: no division.  Tiles that
+        // lie inside the level with their halo (wave-uniform test) skip the reflections and the bounds checks.
+        auto stage = [&](int r, int c4) {
             const int y = reflect101(ty0 + r - 3, lv.h), x0 = tx0 - 4 + 4 * c4;
-            const uint8_t* row = img + (size_t)y * lv.pitch;
+            const uint8_t* row = img + (uint32_t)(y * lv.pitch);
             uint32_t v;
             if (x0 >= 0 && x0 + 3 < lv.w) v = *(const uint32_t*)(row + x0);
             else {
@@ -213,6 +226,18 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
                 for (int b = 0; b < 4; b++) v |= (uint32_t)row[reflect101(x0 + b, lv.w)] << (8 * b);
             }
             ((uint32_t*)(s_px + r * BT_PW))[c4] = v;
+        };
+        if (ty0 >= 3 && ty0 + BT_ROWS - 3 <= lv.h && tx0 >= 4 && tx0 + BT_W + 4 <= lv.w) {
+            const uint8_t* base = img + (uint32_t)((ty0 - 3) * lv.pitch + tx0 - 4);
+#pragma unroll
+            for (int r = tid / BT_QW; r < BT_ROWS; r += BT_PP)
+                ((uint32_t*)(s_px + r * BT_PW))[1 + tid % BT_QW] = *(const uint32_t*)(base + (uint32_t)(r * lv.pitch) + 4 + 4 * (tid % BT_QW));
+            if (tid < 2 * BT_ROWS)
+                ((uint32_t*)(s_px + (tid >> 1) * BT_PW))[(tid & 1) * (BT_QW + 1)] =
+                    *(const uint32_t*)(base + (uint32_t)((tid >> 1) * lv.pitch) + (tid & 1) * (BT_W + 4));
+        } else {
+            for (int r = tid / BT_QW; r < BT_ROWS; r += BT_PP) stage(r, 1 + tid % BT_QW);
+            for (int i = tid; i < 2 * BT_ROWS; i += 256) stage(i >> 1, (i & 1) * (BT_QW + 1));
         }
     } else {
         for (int i = tid; i < BT_ROWS * (BT_W + 6); i += 256) {
@@ -258,18 +283,19 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
             uint4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) v[j] = *(const uint4*)(&s_row[(p + j) * BT_W + c0]);
-            uint32_t pe = 0, po = 0;
+            uint32_t se[4], so[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t a0 = k == 0 ? v[0].x : k == 1 ? v[0].y : k == 2 ? v[0].z : v[0].w;
                 const uint32_t a1 = k == 0 ? v[1].x : k == 1 ? v[1].y : k == 2 ? v[1].z : v[1].w;
                 const uint32_t a2 = k == 0 ? v[2].x : k == 1 ? v[2].y : k == 2 ? v[2].z : v[2].w;
                 const uint32_t a3 = k == 0 ? v[3].x : k == 1 ? v[3].y : k == 2 ? v[3].z : v[3].w;
-                uint32_t se = udot2(a0, e0, udot2(a1, e1, udot2(a2, e2, udot2(a3, e3, 1u << 15))));
-                uint32_t so = udot2(a0, d0, udot2(a1, d1, udot2(a2, d2, udot2(a3, d3, 1u << 15))));
-                pe |= min(se >> 16, 255u) << (8 * k);
-                po |= min(so >> 16, 255u) << (8 * k);
+                se[k] = udot2(a0, e0, udot2(a1, e1, udot2(a2, e2, udot2(a3, e3, 1u << 15))));
+                so[k] = udot2(a0, d0, udot2(a1, d1, udot2(a2, d2, udot2(a3, d3, 1u << 15))));
             }
+            // (sum >> 16) is at most 257: the high halves of two sums -> one dword (v_perm), both saturated to bytes at once
+            const uint32_t pe = hi16_pair_sat_u8(se[0], se[1]) | (hi16_pair_sat_u8(se[2], se[3]) << 16);
+            const uint32_t po = hi16_pair_sat_u8(so[0], so[1]) | (hi16_pair_sat_u8(so[2], so[3]) << 16);
             uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff + (size_t)y * lv.bpitch + x;
             *(uint32_t*)out = pe;  // bpitch is a multiple of 16 >= w: the <= 3 bytes past w land in row padding
             if (y + 1 < lv.h) *(uint32_t*)(out + lv.bpitch) = po;

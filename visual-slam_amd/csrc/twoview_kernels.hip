@@ -27,10 +27,11 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define TVF_BLOCK 512  // k_tv_finish: one block per pair, about one correspondence per thread in the per-point phases
 
-#define TV_REC 11  // doubles per survivor record: E (9), partial cost, hypothesis index (as its bit pattern)
+#define TV_REC 10  // doubles per survivor record: E (9), hypothesis index (as its bit pattern)
 
 struct TvWork {
     double* xn;        // [pairs][cap][4] normalised x1,y1,x2,y2
+    float* xf;         // [pairs][cap][4] the same rounded to float32 (first scoring stage)
     float* px;         // [pairs][cap][4] pixel u1,v1,u2,v2
     int* qidx;         // [pairs][cap] query keypoint index of correspondence i
     int* m;            // [pairs]
@@ -42,12 +43,13 @@ struct TvWork {
     double* wE;        // [pairs][ceil(n_hyp / 64)][9] its matrix: k_tv_finish takes the one whose key equals best
     unsigned long long* best;  // [pairs] (float32 bits of the MSAC cost << 32) | hypothesis index, minimum wins
     double* norm;      // [pairs][8] fundamental-matrix model: common scale s, centroid 1 (x, y), centroid 2 (x, y) of the
-                       // Hartley normalisation x_n = s (x - c); Sampson distances scale by s^2, so thr_n = thr_px * s
+                       // Hartley normalisation x_n = s (x - c); Sampson distances scale by s^2, so thr_n = thr_px * s;
+                       // [5] = max(1, largest |coordinate| in xn) for the error bounds of the float32 stage
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
     size_t p = (size_t)n_pairs, nt = (size_t)((n_hyp + 63) / 64);
-    return p * cap * 4 * sizeof(double) + p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 + 16 +
+    return p * cap * 4 * sizeof(double) + 2 * p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 + 16 +
            p * (size_t)n_hyp * TV_REC * sizeof(double) + p * nt * (sizeof(int2) + sizeof(unsigned long long) + 9 * sizeof(double)) +
            p * sizeof(unsigned long long) + p * 8 * sizeof(double) + 1024;
 }
@@ -64,6 +66,7 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     w.norm = (double*)b; b += p * 8 * sizeof(double);
     w.task = (int2*)b; b += p * nt * sizeof(int2);
     w.px = (float*)b; b += p * cap * 4 * sizeof(float);
+    w.xf = (float*)b; b += p * cap * 4 * sizeof(float);
     w.qidx = (int*)b; b += p * cap * sizeof(int);
     w.m = (int*)b; b += p * sizeof(int);
     w.n_alive = (int*)b; b += p * sizeof(int);
@@ -423,6 +426,26 @@ __device__ void tv_hartley(const TwoViewArgs& a, const TvWork& w, int pair, int 
     }
 }
 
+// float32 copy of the scoring coordinates and their largest magnitude (first scoring stage); called by all threads of the prep
+// block once xn[0 .. m) is final
+__device__ void tv_f32_copy(const TwoViewArgs& a, const TvWork& w, int pair, int m) {
+    __shared__ float s_mx[TV_BLOCK / 64];
+    const int tid = threadIdx.x;
+    const double* xn = w.xn + (size_t)pair * a.cap * 4;
+    float* xf = w.xf + (size_t)pair * a.cap * 4;
+    __syncthreads();  // xn of this block is complete
+    float mx = 1.0f;
+    for (int i = tid; i < 4 * m; i += TV_BLOCK) {
+        const float v = (float)xn[i];
+        xf[i] = v;
+        mx = fmaxf(mx, fabsf(v));  // (a NaN coordinate is dropped here and poisons nothing: see k_tv_hyp)
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) s_mx[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) w.norm[(size_t)pair * 8 + 5] = (double)fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3])) * 1.0000002;
+}
+
 __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     const int pair = blockIdx.x, tid = threadIdx.x;
     __shared__ int s_w[TV_BLOCK / 64];
@@ -446,6 +469,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         }
         if (tid == 0) w.m[pair] = m;
         if (a.model) tv_hartley(a, w, pair, m);
+        tv_f32_copy(a, w, pair, m);
         return;
     }
     const mo_keypoint* k1 = a.d_kps + (size_t)pair * a.cap;
@@ -463,6 +487,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         }
         if (tid == 0) w.m[pair] = m;
         if (a.model) tv_hartley(a, w, pair, m);
+        tv_f32_copy(a, w, pair, m);
         return;
     }
     // from matcher output: pair p = frame p (query) vs frame p+1 (train); survivors in query order
@@ -494,14 +519,16 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     }
     if (tid == 0) w.m[pair] = s_base;
     if (a.model) tv_hartley(a, w, pair, s_base);
+    tv_f32_copy(a, w, pair, s_base);
 }
 
 // ---------------------------------------------------------------- hypotheses ----------------------
 
-// correspondences summed by the first scoring stage: a quarter of them, at least 32
-__device__ __forceinline__ int tv_first(int m) { return min(m, max(32, (m + 3) >> 2)); }
+// correspondences summed by the first scoring stage: TV_FIRST_NUM eighths of them, at least 32
+#define TV_FIRST_NUM 2
+__device__ __forceinline__ int tv_first(int m, int num) { return min(m, max(32, (m * num + 7) >> 3)); }
 
-__global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, int staged) {
+__global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, int staged, int first_num) {
     __shared__ unsigned long long s_best[TV_BLOCK / 64];
     const int pair = blockIdx.y, tid = threadIdx.x;
     const int h = blockIdx.x * TV_BLOCK + tid;
@@ -524,27 +551,77 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     // MSAC score: sum of Sampson distances truncated at thr^2 (a pure inlier count prefers slightly perturbed
     // models that catch more chance inliers).  Compared as float32, ties -> lowest hypothesis index.
     // The correspondences are the same for every lane: they arrive through wave-uniform scalar loads (constant address
-    // space; k_tv_prep wrote them in an earlier launch) and feed the fp64 FMAs as scalar operands, one per instruction.
-    //
-    // Staged scoring (exact): every hypothesis first sums the first F = tv_first(m) correspondences.  The hypothesis with
-    // the smallest partial cost of the block is then scored completely by the whole block; its total (rounded up) is an
-    // upper bound of the best total of the pair.  A hypothesis whose PARTIAL cost already exceeds the bound cannot win
-    // (costs only grow), so only the others -- typically 5-20 % -- are finished, compacted into the first wavefronts.
-    typedef const __attribute__((address_space(4))) double* cdp;
-    const cdp pts = (cdp)(uintptr_t)xn;
-    const int F = staged ? tv_first(m) : m;
-    double cost = 0.0;
-    if (valid) {
-#pragma unroll 4
-        for (int i = 0; i < F; i++) {
-            double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
-            cost += fmin(err, thr2);
-        }
-    }
+    // space; k_tv_prep wrote them in an earlier launch) and feed the FMAs as scalar operands, one per instruction.
     const int lane = tid & 63, wv = tid >> 6;
     const size_t ntask_max = (size_t)((a.n_hyp + 63) / 64);
     unsigned long long key = ~0ull;
-    if (valid && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
+    if (!staged) {  // few hypotheses: every one is scored completely here, the block's best goes straight to the pair's minimum
+        typedef const __attribute__((address_space(4))) double* cdp;
+        const cdp pts = (cdp)(uintptr_t)xn;
+        double cost = 0.0;
+        if (valid) {
+#pragma unroll 4
+            for (int i = 0; i < m; i++) {
+                double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
+                cost += fmin(err, thr2);
+            }
+        }
+        if (valid && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
+        const unsigned long long own = key;
+        for (int o = 32; o > 0; o >>= 1) {
+            unsigned long long other = __shfl_xor(key, o, 64);
+            key = other < key ? other : key;
+        }
+        if (lane == 0) s_best[wv] = key;
+        __syncthreads();
+        for (int k = 0; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;  // block minimum, in every thread
+        if (key != ~0ull && own == key) {  // (a block index is a valid slot: there are at least as many 64-tasks as 256-blocks)
+            double* bE = w.wE + ((size_t)pair * ntask_max + blockIdx.x) * 9;
+            for (int j = 0; j < 9; j++) bE[j] = E[j];
+            w.wkey[(size_t)pair * ntask_max + blockIdx.x] = key;
+            atomicMin(&w.best[pair], key);
+        }
+        return;
+    }
+    // Staged scoring (exact).  Stage 1, here, in float32: a LOWER BOUND of the cost over the first F correspondences.
+    // With eps = 2^-24, X = the largest |coordinate| (>= 1, from k_tv_prep) and s1 = sum |E_ij|, float32 evaluation of
+    // (E x1)_k is off by at most a = 4e-7 X s1 (five roundings of terms <= X s1, inputs rounded once), the residual
+    // r = x2' E x1 by at most delta = 2e-6 X^2 s1, and the true denominator is at most (sqrt(den) + 2a)^2 <=
+    // 1.001 den + 4004 a^2.  So  max(|r| - delta, 0)^2 / (1.0011 den + 4004 a^2)  never exceeds the exact Sampson
+    // distance (the extra 1e-4 covers v_rcp_f32 and the roundings of this line), the truncated sum of F of them times
+    // (1 - 1e-4) (float32 accumulation of non-negative terms) never exceeds the exact partial cost, and costs only grow
+    // with more correspondences.  The block's hypothesis with the smallest bound is scored completely, in fp64, by the
+    // whole block: its total (rounded up) is an upper bound of the best total of the pair, and a hypothesis whose lower
+    // bound exceeds it cannot win.  Only the others - typically 5-20 % - are scored in fp64, by k_tv_score.
+    typedef const __attribute__((address_space(4))) float* cfp;
+    const cfp pf = (cfp)(uintptr_t)(w.xf + (size_t)pair * a.cap * 4);
+    const int F = tv_first(m, first_num);
+    const float X = (float)w.norm[(size_t)pair * 8 + 5];
+    float lb = 0.0f;
+    if (valid && X < 1e6f) {  // (absurd coordinates: no float32 pruning, every hypothesis goes to the fp64 stage)
+        float e[9], s1 = 0.0f;
+        for (int j = 0; j < 9; j++) { e[j] = (float)E[j]; s1 += fabsf(e[j]); }
+        s1 *= 1.000001f;
+        const float ae = 4e-7f * X * s1, delta = 2e-6f * X * X * s1, cden = 4004.0f * ae * ae;
+        const float thr2f = __uint_as_float(__float_as_uint((float)thr2) - 1u);  // below thr^2 (thr2 > 0: a normal number)
+#pragma unroll 4
+        for (int i = 0; i < F; i++) {
+            const float x1 = pf[4 * i], y1 = pf[4 * i + 1], x2 = pf[4 * i + 2], y2 = pf[4 * i + 3];
+            const float ex0 = fmaf(e[0], x1, fmaf(e[1], y1, e[2]));
+            const float ex1 = fmaf(e[3], x1, fmaf(e[4], y1, e[5]));
+            const float ex2 = fmaf(e[6], x1, fmaf(e[7], y1, e[8]));
+            const float et0 = fmaf(e[0], x2, fmaf(e[3], y2, e[6]));
+            const float et1 = fmaf(e[1], x2, fmaf(e[4], y2, e[7]));
+            const float r = fmaf(x2, ex0, fmaf(y2, ex1, ex2));
+            const float den = fmaf(ex0, ex0, fmaf(ex1, ex1, fmaf(et0, et0, et1 * et1)));
+            const float rl = fmaxf(fabsf(r) - delta, 0.0f);
+            const float t = rl * rl * __builtin_amdgcn_rcpf(fmaf(den, 1.0011f, cden));
+            lb += fminf(t, thr2f);
+        }
+        lb *= 0.9999f;
+        if (!(lb >= 0.0f)) lb = 0.0f;  // NaN (overflow somewhere): no information, keep the hypothesis
+    }
+    if (valid) key = ((unsigned long long)__float_as_uint(lb) << 32) | (unsigned long long)(unsigned)h;
     const unsigned long long own = key;
     for (int o = 32; o > 0; o >>= 1) {
         unsigned long long other = __shfl_xor(key, o, 64);
@@ -554,47 +631,37 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     __syncthreads();
     for (int k = 0; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;  // block minimum, in every thread
     if (key == ~0ull) return;  // no valid hypothesis in this block (block-uniform)
-    __shared__ double s_cand[10];
-    if (!staged) {  // every cost is already complete: the block's best goes straight to the pair's minimum
-        if (own == key) {  // (a block index is a valid slot: there are at least as many 64-tasks as 256-blocks)
-            double* bE = w.wE + ((size_t)pair * ntask_max + blockIdx.x) * 9;
-            for (int j = 0; j < 9; j++) bE[j] = E[j];
-            w.wkey[(size_t)pair * ntask_max + blockIdx.x] = key;
-            atomicMin(&w.best[pair], key);
-        }
-        return;
-    }
     // the block's candidate: total cost by all threads -> bound
+    __shared__ double s_cand[9];
     __shared__ double s_sum[TV_BLOCK / 64];
     __shared__ unsigned s_bound;
-    if (own == key) {
+    if (own == key)
         for (int j = 0; j < 9; j++) s_cand[j] = E[j];
-        s_cand[9] = cost;
-    }
     __syncthreads();
     {
         double Ec[9];
         for (int j = 0; j < 9; j++) Ec[j] = s_cand[j];
-        double rest = 0.0;
-        for (int i = F + tid; i < m; i += TV_BLOCK)
-            rest += fmin(sampson_fast(Ec, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]), thr2);
-        for (int o = 32; o > 0; o >>= 1) rest += __shfl_xor(rest, o, 64);
-        if (lane == 0) s_sum[wv] = rest;
+        double tot = 0.0;
+        for (int i = tid; i < m; i += TV_BLOCK)
+            tot += fmin(sampson_fast(Ec, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]), thr2);
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+        if (lane == 0) s_sum[wv] = tot;
     }
     __syncthreads();
     if (tid == 0) {
-        double total = s_cand[9];
+        double total = 0.0;
         for (int k = 0; k < TV_BLOCK / 64; k++) total += s_sum[k];
         // this sum is associated differently from the canonical (sequential) one: two float32 ulps upwards cover that
-        // and the rounding to float32, so the bound never undercuts the candidate's canonical cost
-        s_bound = __float_as_uint((float)total) + 2u;
+        // and the rounding to float32, so the bound never undercuts the candidate's canonical cost.  A NaN total (the
+        // canonical sum of the candidate is then NaN too and it cannot win) gives no bound: everything survives.
+        s_bound = total == total ? __float_as_uint((float)total) + 2u : 0x7F800000u;
     }
     __syncthreads();
-    // survivors (float32(partial cost) <= bound; costs are >= 0, so bit order = value order) -> the pair's dense list in
-    // HBM (order is irrelevant for a minimum; the candidate itself always survives): one atomic per block
+    // survivors (lower bound <= bound; both >= 0, so bit order = value order) -> the pair's dense list in HBM (order is
+    // irrelevant for a minimum; the candidate itself always survives): one atomic per block
     __shared__ int s_wcnt[TV_BLOCK / 64];
     __shared__ int s_gbase;
-    const bool alive = own != ~0ull && __float_as_uint((float)cost) <= s_bound;
+    const bool alive = own != ~0ull && __float_as_uint(lb) <= s_bound;
     const unsigned long long mk = __ballot(alive);
     if (lane == 0) s_wcnt[wv] = __popcll(mk);
     __syncthreads();
@@ -605,8 +672,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     if (alive) {
         double* rec = w.surv + ((size_t)pair * a.n_hyp + s_gbase + sbase + __popcll(mk & ((1ull << lane) - 1ull))) * TV_REC;
         for (int j = 0; j < 9; j++) rec[j] = E[j];
-        rec[9] = cost;
-        rec[10] = __longlong_as_double((long long)h);
+        rec[9] = __longlong_as_double((long long)h);
     }
 }
 
@@ -633,8 +699,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_tasks(TwoViewArgs a, TvWork w) 
     if (tid == 0) *w.n_tasks = total;
 }
 
-// Second stage: every lane continues one survivor's sequential sum over the remaining correspondences (bit-identical to an
-// unstaged sum); the wavefront's best goes to the pair's minimum and, with its matrix, to the slot k_tv_finish looks it up in.
+// Second stage: every lane sums one survivor's cost over all correspondences, sequentially in fp64 (the canonical sum the keys
+// are defined on); the wavefront's best goes to the pair's minimum and, with its matrix, to the slot k_tv_finish looks it up in.
 __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
     const int lane = threadIdx.x;
     if ((int)blockIdx.x >= *w.n_tasks) return;
@@ -647,15 +713,14 @@ __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
     typedef const __attribute__((address_space(4))) double* cdp;
     const cdp pts = (cdp)(uintptr_t)xn;
-    const int F = tv_first(m);
     const bool on = t0 + lane < total;
     const double* rec = w.surv + ((size_t)pair * a.n_hyp + (on ? t0 + lane : t0)) * TV_REC;
     double E[9];
     for (int j = 0; j < 9; j++) E[j] = rec[j];
-    double cost = rec[9];
-    const unsigned h = (unsigned)__double_as_longlong(rec[10]);
+    double cost = 0.0;
+    const unsigned h = (unsigned)__double_as_longlong(rec[9]);
 #pragma unroll 4
-    for (int i = F; i < m; i++) {
+    for (int i = 0; i < m; i++) {
         double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
         cost += fmin(err, thr2);
     }
@@ -1036,7 +1101,8 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
         return MO_OK;
     }
     const int staged = a.n_hyp >= 512;  // below that the bound of one or two blocks prunes too little to pay for the second stage
-    hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged);
+    static const int first_num = [] { const char* e = getenv("VSLAM_AMD_TV_FIRST"); int v = e ? atoi(e) : TV_FIRST_NUM; return v >= 1 && v <= 8 ? v : TV_FIRST_NUM; }();
+    hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged, first_num);
     if (staged) {
         hipLaunchKernelGGL(k_tv_tasks, dim3(1), dim3(TV_BLOCK), 0, c->stream, a, w);
         hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64), 0, c->stream, a, w);
