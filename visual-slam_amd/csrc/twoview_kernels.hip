@@ -239,12 +239,78 @@ __device__ bool svd3_rank2(const double* E, double* U, double* V, double* sig) {
     return true;
 }
 
-// nearest essential matrix (singular values 1, 1, 0)
+// Right singular vector v3 of the smallest singular value of a 3x3 matrix, without an eigen-solver: the adjugate of
+// A = E^T E is  l1 l2 v3 v3' + l1 l3 v2 v2' + l2 l3 v1 v1'  (l = eigenvalues of A, descending), so v3 is its dominant
+// eigenvector with the gap l2 / l3 = (sigma2 / sigma3)^2.  Eight squarings of the (symmetric) matrix raise the gap to
+// the 256th power - below 1e-12 up to sigma3 / sigma2 = 0.95, i.e. far beyond any matrix that resembles an essential
+// matrix - and leave v3 v3' up to scale; its longest column, normalised, is v3.  Straight-line code, about 250 fp64
+// instructions (the cyclic Jacobi sweeps this replaces in the hypothesis kernel: about 2000).  Returns false for rank < 2.
+__device__ bool smallest_right3(const double* E, double* v3) {
+    const double a00 = E[0] * E[0] + E[3] * E[3] + E[6] * E[6], a01 = E[0] * E[1] + E[3] * E[4] + E[6] * E[7];
+    const double a02 = E[0] * E[2] + E[3] * E[5] + E[6] * E[8], a11 = E[1] * E[1] + E[4] * E[4] + E[7] * E[7];
+    const double a12 = E[1] * E[2] + E[4] * E[5] + E[7] * E[8], a22 = E[2] * E[2] + E[5] * E[5] + E[8] * E[8];
+    const double tr = a00 + a11 + a22;
+    double b00 = a11 * a22 - a12 * a12, b01 = a02 * a12 - a01 * a22, b02 = a01 * a12 - a02 * a11;
+    double b11 = a00 * a22 - a02 * a02, b12 = a01 * a02 - a00 * a12, b22 = a00 * a11 - a01 * a01;
+    const double c1 = b00 + b11 + b22;  // l1 l2 + l1 l3 + l2 l3
+    if (!(tr > 1e-300) || !(c1 > 1e-24 * tr * tr)) return false;  // sigma2 <= 1e-12 sigma1
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // trace -> 1, then two squarings (the trace stays above 1/9)
+        const double t = 1.0 / (b00 + b11 + b22);
+        b00 *= t; b01 *= t; b02 *= t; b11 *= t; b12 *= t; b22 *= t;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const double c00 = b00 * b00 + b01 * b01 + b02 * b02, c01 = b00 * b01 + b01 * b11 + b02 * b12;
+            const double c02 = b00 * b02 + b01 * b12 + b02 * b22, c11 = b01 * b01 + b11 * b11 + b12 * b12;
+            const double c12 = b01 * b02 + b11 * b12 + b12 * b22, c22 = b02 * b02 + b12 * b12 + b22 * b22;
+            b00 = c00; b01 = c01; b02 = c02; b11 = c11; b12 = c12; b22 = c22;
+        }
+    }
+    const double n0 = b00 * b00 + b01 * b01 + b02 * b02, n1 = b01 * b01 + b11 * b11 + b12 * b12, n2 = b02 * b02 + b12 * b12 + b22 * b22;
+    const bool p0 = n0 >= n1 && n0 >= n2, p1 = !p0 && n1 >= n2;
+    const double x = p0 ? b00 : p1 ? b01 : b02, y = p0 ? b01 : p1 ? b11 : b12, z = p0 ? b02 : p1 ? b12 : b22;
+    const double nn = p0 ? n0 : p1 ? n1 : n2;
+    if (!(nn > 0)) return false;
+    const double r = 1.0 / sqrt(nn);
+    v3[0] = x * r; v3[1] = y * r; v3[2] = z * r;
+    return true;
+}
+
+// nearest essential matrix U diag(1, 1, 0) V' in closed form: with an orthonormal basis (a, b) of the plane orthogonal to
+// v3, E maps that plane onto the plane orthogonal to u3, so u3 = (E a) x (E b) normalised; in the bases (a, b) and
+// (c, d) = (E a / |E a|, u3 x c) the restriction of E is the upper-triangular M = [p q; 0 s] with p, s > 0, whose
+// orthogonal polar factor is the rotation [p + s, q; -q, p + s] / h - and U diag(1, 1, 0) V' = [c d] polar(M) [a b]'.
 __device__ bool project_essential(double* E) {
-    double U[9], V[9], s[3];
-    if (!svd3_rank2(E, U, V, s)) return false;
+    double v[3];
+    if (!smallest_right3(E, v)) return false;
+    // a = v x e_k (normalised) for the axis k with the smallest |v_k|, b = v x a
+    const double ax = fabs(v[0]), ay = fabs(v[1]), az = fabs(v[2]);
+    const bool kx = ax <= ay && ax <= az, ky = !kx && ay <= az;
+    double a[3] = {kx ? 0.0 : ky ? -v[2] : v[1], kx ? v[2] : ky ? 0.0 : -v[0], kx ? -v[1] : ky ? v[0] : 0.0};
+    const double ra = 1.0 / sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);  // 1 - v_k^2 >= 2/3
+    a[0] *= ra; a[1] *= ra; a[2] *= ra;
+    double b[3];
+    cross3(v, a, b);
+    double Ea[3], Eb[3], u3[3];
+    for (int i = 0; i < 3; i++) {
+        Ea[i] = E[i * 3] * a[0] + E[i * 3 + 1] * a[1] + E[i * 3 + 2] * a[2];
+        Eb[i] = E[i * 3] * b[0] + E[i * 3 + 1] * b[1] + E[i * 3 + 2] * b[2];
+    }
+    cross3(Ea, Eb, u3);
+    const double p2 = Ea[0] * Ea[0] + Ea[1] * Ea[1] + Ea[2] * Ea[2], e2 = Eb[0] * Eb[0] + Eb[1] * Eb[1] + Eb[2] * Eb[2];
+    const double nu2 = u3[0] * u3[0] + u3[1] * u3[1] + u3[2] * u3[2];  // (sigma1 sigma2)^2
+    if (!(nu2 > 1e-24 * (p2 + e2) * (p2 + e2)) || !(p2 > 0)) return false;
+    const double ru = 1.0 / sqrt(nu2), rp = 1.0 / sqrt(p2);
+    double c[3] = {Ea[0] * rp, Ea[1] * rp, Ea[2] * rp}, d[3];
+    u3[0] *= ru; u3[1] *= ru; u3[2] *= ru;
+    cross3(u3, c, d);
+    const double pp = p2 * rp, q = c[0] * Eb[0] + c[1] * Eb[1] + c[2] * Eb[2], sd = d[0] * Eb[0] + d[1] * Eb[1] + d[2] * Eb[2];
+    const double rh = 1.0 / sqrt((pp + sd) * (pp + sd) + q * q);
+    const double r0 = (pp + sd) * rh, r1 = q * rh;
+    double g[3], h[3];  // rows of polar(M) [a b]'
+    for (int j = 0; j < 3; j++) { g[j] = r0 * a[j] + r1 * b[j]; h[j] = r0 * b[j] - r1 * a[j]; }
     for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) E[i * 3 + j] = U[i * 3] * V[j * 3] + U[i * 3 + 1] * V[j * 3 + 1];
+        for (int j = 0; j < 3; j++) E[i * 3 + j] = c[i] * g[j] + d[i] * h[j];
     return true;
 }
 
@@ -372,12 +438,14 @@ __device__ __forceinline__ double tv_thr(const TwoViewArgs& a, const TvWork& w, 
     return a.model ? a.thr_px * w.norm[(size_t)pair * 8] : a.thr_px / ((a.K[0] + a.K[4]) / 2.0);
 }
 
-// nearest rank-2 matrix (smallest singular value -> 0): the fundamental-matrix constraint
+// nearest rank-2 matrix (smallest singular value -> 0): the fundamental-matrix constraint.  F - sigma3 u3 v3' = F (I - v3 v3')
 __device__ bool project_rank2(double* F) {
-    double U[9], V[9], s[3];
-    if (!svd3_rank2(F, U, V, s)) return false;
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) F[i * 3 + j] = s[0] * U[i * 3] * V[j * 3] + s[1] * U[i * 3 + 1] * V[j * 3 + 1];
+    double v[3];
+    if (!smallest_right3(F, v)) return false;
+    for (int i = 0; i < 3; i++) {
+        const double fv = F[i * 3] * v[0] + F[i * 3 + 1] * v[1] + F[i * 3 + 2] * v[2];
+        for (int j = 0; j < 3; j++) F[i * 3 + j] -= fv * v[j];
+    }
     return true;
 }
 
