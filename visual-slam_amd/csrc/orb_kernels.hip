@@ -1028,15 +1028,18 @@ __device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch,
     double sd, cd;
     sincos((double)angle, &sd, &cd);  // f64 then rounded to f32, as cv2's (float)cos(angle) / (float)sin(angle)
     const float a = (float)cd, b = (float)sd;
+    const int cxm = cx - 0x4B400000, cym = cy - 0x4B400000;
     unsigned val = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int8_t* pt = &c_pattern[(gl * 16 + k) * 4];
         float fx0 = (float)pt[0], fy0 = (float)pt[1], fx1 = (float)pt[2], fy1 = (float)pt[3];
-        int ix0 = __float2int_rn(fx0 * a - fy0 * b), iy0 = __float2int_rn(fx0 * b + fy0 * a);
-        int ix1 = __float2int_rn(fx1 * a - fy1 * b), iy1 = __float2int_rn(fx1 * b + fy1 * a);
-        int t0 = patch[__mul24(cy + iy0, ppitch) + cx + ix0];  // 24-bit multiply-add: full rate, unlike v_mul_lo_u32
-        int t1 = patch[__mul24(cy + iy1, ppitch) + cx + ix1];
+        // cvRound (round half to even) of |v| < 2^22 as the low bits of v + 1.5 * 2^23: one full-rate v_add_f32 instead of
+        // v_rndne_f32 + v_cvt_i32_f32 (both half rate); the bias 0x4B400000 is folded into cxm / cym
+        const int jx0 = __float_as_int((fx0 * a - fy0 * b) + 12582912.f), jy0 = __float_as_int((fx0 * b + fy0 * a) + 12582912.f);
+        const int jx1 = __float_as_int((fx1 * a - fy1 * b) + 12582912.f), jy1 = __float_as_int((fx1 * b + fy1 * a) + 12582912.f);
+        int t0 = patch[__mul24(cym + jy0, ppitch) + cxm + jx0];  // 24-bit multiply-add: full rate, unlike v_mul_lo_u32
+        int t1 = patch[__mul24(cym + jy1, ppitch) + cxm + jx1];
         val |= (t0 < t1 ? 1u : 0u) << k;
     }
     return (uint16_t)val;  // little endian: bits 0..7 = byte 2gl, bits 8..15 = byte 2gl+1
@@ -1057,6 +1060,7 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
                                                   int* flags, const int* __restrict__ lv_tab, uint32_t inv_per) {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_PATCH_BYTES];
     __shared__ int s_lv[MO_MAX_LEVELS][DLV_N];
+    __shared__ __attribute__((aligned(16))) uint32_t s_icw[32][16];  // intensity-centroid weights of the 31 disc rows (+ a zero row)
     // XCD affinity (speed only, any mapping is correct): consecutive workgroup ids go round-robin to the 8 XCDs, each with
     // its own L2.  Re-indexing so that all workgroups of a frame share one id residue keeps the frame's two pyramids
     // (2 MB) in ONE L2 while its keypoints are described, instead of being fetched into eight.
@@ -1074,6 +1078,8 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
     // the keypoint record, then the patches: ~11 round trips).  Now: the per-level counts of the frame (wave-uniform, all
     // issued at once) and the level table (copied to LDS) travel together, then the record, then the patches: 3.
     if (threadIdx.x < MO_MAX_LEVELS * DLV_N) (&s_lv[0][0])[threadIdx.x] = lv_tab[threadIdx.x];
+    (&s_icw[0][0])[threadIdx.x] = (uint32_t)lv_tab[MO_MAX_LEVELS * DLV_N + threadIdx.x];
+    (&s_icw[0][0])[threadIdx.x + 256] = (uint32_t)lv_tab[MO_MAX_LEVELS * DLV_N + 256 + threadIdx.x];
     const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
     int cn[MO_MAX_LEVELS];
 #pragma unroll
@@ -1116,22 +1122,49 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
         patch_load<39, 11>(bl, lv.bpitch, xb0, cy - 19, gl, true, blr);
     }
     patch_store<31, 9>(s_p, DP_RAW_PITCH, gl, raw);
-    // intensity centroid over the radius-15 disc: rows gl and gl + 16 of the 31 on each lane
+    // intensity centroid over the radius-15 disc: rows gl and gl + 16 of the 31 on each lane.  A row is read as nine dwords,
+    // realigned so that dword c holds u = 4c - 15 .. 4c - 12, and reduced with two v_dot4_u32_u8 per dword against the row's
+    // weight bytes (u + 16 inside the disc, else 0) and mask bytes (1 inside): sum u p = dot(w) - 16 dot(mask).  The byte
+    // loop this replaces ran max over the lanes of (2 d0 + 1) + (2 d1 + 1) = 54 trips of six instructions.
     int m10 = 0, m01 = 0;
+    if (offr <= 3) {  // group-uniform (always, unless the window was moved left at the end of a row)
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int row_i = gl + rr * DG;
-        if (row_i < 31) {
-            const int v = row_i - 15;
-            const int d = rr == 0 ? dsc0 : dsc1;
-            const uint8_t* row = s_p + row_i * DP_RAW_PITCH + 15 + offr;
-            int rs = 0;
-            for (int u = -d; u <= d; u++) {
-                int p = row[u];
-                m10 += u * p;
-                rs += p;
+        for (int rr = 0; rr < 2; rr++) {
+            const int row_i = gl + rr * DG;  // row 31: all-zero weights, the dwords read lie inside the group's patch buffer
+            const uint32_t* rowp = (const uint32_t*)(s_p + row_i * DP_RAW_PITCH);
+            const uint4 w0 = *(const uint4*)&s_icw[row_i][0], w1 = *(const uint4*)&s_icw[row_i][4];
+            const uint4 k0 = *(const uint4*)&s_icw[row_i][8], k1 = *(const uint4*)&s_icw[row_i][12];
+            const uint32_t wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const uint32_t mk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+            uint32_t px[9];
+#pragma unroll
+            for (int c4 = 0; c4 < 9; c4++) px[c4] = rowp[c4];
+            uint32_t sw = 0, rs = 0;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; c4++) {
+                const uint32_t a = __builtin_amdgcn_alignbyte(px[c4 + 1], px[c4], (uint32_t)offr);
+                sw = __builtin_amdgcn_udot4(a, wt[c4], sw, false);
+                rs = __builtin_amdgcn_udot4(a, mk[c4], rs, false);
             }
-            m01 += v * rs;
+            m10 += (int)sw - 16 * (int)rs;
+            m01 += (row_i - 15) * (int)rs;
+        }
+    } else {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int row_i = gl + rr * DG;
+            if (row_i < 31) {
+                const int v = row_i - 15;
+                const int d = rr == 0 ? dsc0 : dsc1;
+                const uint8_t* row = s_p + row_i * DP_RAW_PITCH + 15 + offr;
+                int rs = 0;
+                for (int u = -d; u <= d; u++) {
+                    int p = row[u];
+                    m10 += u * p;
+                    rs += p;
+                }
+                m01 += v * rs;
+            }
         }
     }
     m10 = group_sum(m10);
@@ -1157,7 +1190,19 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
     const Plan& P = c->plan;
     const dim3 grid((cap + DK_PER_WG - 1) / DK_PER_WG, batch);
     if (!c->d_lv_tab) {  // (re)built with the plan: free_plan_buffers drops it
-        int tab[MO_MAX_LEVELS * DLV_N] = {0};
+        int tab[MO_MAX_LEVELS * DLV_N + 512] = {0};  // level table, then the intensity-centroid weights [32 rows][8 weight + 8 mask dwords]
+        for (int r = 0; r < 31; r++) {
+            const int d = P.umax[r < 15 ? 15 - r : r - 15];
+            for (int c4 = 0; c4 < 8; c4++) {
+                uint32_t wv = 0, mv = 0;
+                for (int b = 0; b < 4; b++) {
+                    const int u = 4 * c4 - 15 + b;
+                    if (u >= -d && u <= d) { wv |= (uint32_t)(u + 16) << (8 * b); mv |= 1u << (8 * b); }
+                }
+                tab[MO_MAX_LEVELS * DLV_N + r * 16 + c4] = (int)wv;
+                tab[MO_MAX_LEVELS * DLV_N + r * 16 + 8 + c4] = (int)mv;
+            }
+        }
         for (int L = 0; L < P.nlevels; L++) {
             int* e = tab + L * DLV_N;
             e[DLV_PITCH] = P.lv[L].pitch; e[DLV_OFF] = P.lv[L].off; e[DLV_BPITCH] = P.lv[L].bpitch; e[DLV_BOFF] = P.lv[L].boff;
