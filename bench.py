@@ -344,6 +344,23 @@ def main():
         traffic = kf.get("hbm_bytes")  # FETCH_SIZE x 2 (guide: 16-byte-per-lane streams count half) + WRITE_SIZE, per launch
         valu = kf.get("valu_insts")    # SQ_INSTS_VALU per launch (wave instructions)
         valu_frac = valu * 2.0 / (crit_ms * 1e-3 * 2.4e9 * 1024) if valu else None  # 2 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz
+        # the same accounting for every stage (stand-alone duration; counters summed over the stage's kernels and launches per step)
+        STAGE_KERNELS = {"pyramid": ["k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
+                         "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_pair_frames", "k_match_lds"],
+                         "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_tasks", "k_tv_score", "k_tv_finish"]}
+        per_kernel = None
+        if alone and pmc.get("batch_frames") == B:
+            per_kernel, steps_prof = {}, 7.0  # profiles/collect_r02.sh: 5 timed + 2 warm-up steps per pass
+            for st, names in STAGE_KERNELS.items():
+                ks = [pmc["kernels"][n] for n in names if n in pmc.get("kernels", {})]
+                if not ks or st not in alone:
+                    continue
+                per_step = lambda key: sum(k.get(key, 0.0) * k.get("launches", steps_prof) / steps_prof for k in ks)
+                ms_st, algb = alone[st], STAGE_BYTES.get(st, 0) * units_of(st)
+                per_kernel[st] = {"kernels": names, "ms": round(ms_st, 4), "algorithmic_bytes": algb,
+                                  "hbm_frac": round(algb / (ms_st * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                                  "traffic": round(per_step("hbm_bytes")),
+                                  "valu_frac": round(per_step("valu_insts") * 2.0 / (ms_st * 1e-3 * 2.4e9 * 1024), 4)}
         out = {
             "metric": metric_name(),
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -362,11 +379,13 @@ def main():
                          "algorithmic_bytes": alg_bytes, "kernel_ms": round(crit_ms, 4),
                          "kernel_ms_source": "stand-alone (blur serialised)" if alone else "hipEvent span in the timed region",
                          "pipeline_achieved": round(total_alg / (ms_step * 1e-3) / 1e9, 2),
-                         "note": "k_fast = the longest stand-alone kernel on the critical path; algorithmic bytes (SURVEY 8d: "
+                         "note": "k_fast = the image kernel with the longest stand-alone time (the round-1 review's choice; "
+                                 "k_match_lds is longer but touches 0.04 GB per launch: see roofline_per_stage); algorithmic bytes (SURVEY 8d: "
                                  "950 532 B per frame) / its own duration.  valu_frac = SQ_INSTS_VALU (profiles/r02_pmc_per_kernel.json) "
                                  "x 2 cycles / (1024 SIMDs x 2.4 GHz x duration); tools/ubench.hip measures 2.3 cycles only for add/sub/"
                                  "logic/shift-right/f32 add-mul and 4.5 for every other vector instruction at the occupancy these "
                                  "kernels run at, so an integer kernel tops out near 0.5 on this scale (DESIGN.md 4)"},
+            "roofline_per_stage": per_kernel,
             "stage_ms_standalone": {k: round(v, 4) for k, v in alone.items()} if alone else None,
             "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
         }
