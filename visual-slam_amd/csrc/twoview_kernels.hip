@@ -9,13 +9,14 @@
 //
 //   k_tv_prep    per pair: gather the ratio-test survivors (query order) -> normalised f64 correspondences
 //   k_tv_hyp     one thread per hypothesis: counter-based 8-sample, 8x9 null vector by Householder QR (registers),
-//                projection on the essential manifold (3x3 SVD via Jacobi), MSAC cost (truncated Sampson distance)
-//                over the FIRST QUARTER of the correspondences, which arrive as scalar operands; the block's most
-//                promising hypothesis is scored completely -> an upper bound of the pair's best cost; hypotheses whose
-//                partial cost already exceeds it cannot win, only the others (about a fifth) are written out, compacted
-//                (round 1 materialised all 4096 x 9 doubles per pair and every partial cost: 135 MB per step; now ~25 MB)
-//   k_tv_tasks / k_tv_score   the survivors of the whole launch are cut into tasks of 64 (dense table: busy wavefronts first,
-//                evenly spread over the chip) and finished, one per lane -> exact argmin, one atomicMin per wavefront
+//                closed-form projection on the essential manifold (smallest_right3 / project_essential), then a float32
+//                LOWER BOUND of the MSAC cost (truncated Sampson distance) over the first quarter of the correspondences,
+//                which arrive as scalar operands; the block's most promising hypothesis is scored completely in fp64 ->
+//                an upper bound of the pair's best cost; hypotheses whose bound already exceeds it cannot win, only the
+//                others (about a quarter) are written out, compacted
+//   k_tv_tasks / k_tv_score   the survivors of the whole launch are cut into tasks of 64 (dense table: busy workgroups first,
+//                evenly spread over the chip); one workgroup per task sums their canonical fp64 costs (four contiguous
+//                parts, one per wavefront) -> exact argmin, one atomicMin per task
 //   k_tv_finish  one block per pair: consensus set of the best hypothesis -> adaptive-threshold least-squares
 //                8-point refits (9x9 normal matrix, inverse iteration) -> final inliers -> decompose E -> cheirality
 //                vote over the 4 (R, t) candidates with per-point DLT -> final DLT triangulation in pixel space
@@ -27,6 +28,7 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define TVF_BLOCK 512  // k_tv_finish: one block per pair, about one correspondence per thread in the per-point phases
 
+#define TV_PARTS 4  // the canonical cost is summed in this many contiguous parts of the correspondences (tv_cost_lane, k_tv_score)
 #define TV_REC 10  // doubles per survivor record: E (9), hypothesis index (as its bit pattern)
 
 struct TvWork {
@@ -596,6 +598,27 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
 #define TV_FIRST_NUM 2
 __device__ __forceinline__ int tv_first(int m, int num) { return min(m, max(32, (m * num + 7) >> 3)); }
 
+// ---- THE CANONICAL MSAC COST (the value the keys are defined on): the correspondences are cut into TV_PARTS contiguous parts of
+// q = ceil(m / TV_PARTS); each part is summed sequentially in fp64, the parts are combined as (P0 + P1) + (P2 + P3).  One lane
+// can do all of it (tv_cost_lane, few hypotheses), or the four wavefronts of a workgroup one part each (k_tv_score: four times the wavefronts for
+// the same work - the complete sums are chains of dependent fp64 additions and the launch is otherwise short of wavefronts).
+__device__ __forceinline__ int tv_part_len(int m) { return (m + TV_PARTS - 1) / TV_PARTS; }
+__device__ __forceinline__ double tv_cost_part(const double* E, const double* xn, int i0, int i1, double thr2) {
+    typedef const __attribute__((address_space(4))) double* cdp;  // wave-uniform scalar loads: the coordinates feed the FMAs as scalar operands
+    const cdp pts = (cdp)(uintptr_t)xn;
+    double s = 0.0;
+#pragma unroll 4
+    for (int i = i0; i < i1; i++) s += fmin(sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]), thr2);
+    return s;
+}
+__device__ __forceinline__ double tv_combine(const double (&P)[TV_PARTS]) { return (P[0] + P[1]) + (P[2] + P[3]); }
+__device__ __forceinline__ double tv_cost_lane(const double* E, const double* xn, int m, double thr2) {
+    const int q = tv_part_len(m);
+    double P[TV_PARTS];
+    for (int k = 0; k < TV_PARTS; k++) P[k] = tv_cost_part(E, xn, min(m, k * q), min(m, (k + 1) * q), thr2);
+    return tv_combine(P);
+}
+
 __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, int staged, int first_num) {
     __shared__ unsigned long long s_best[TV_BLOCK / 64];
     const int pair = blockIdx.y, tid = threadIdx.x;
@@ -624,16 +647,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
     const size_t ntask_max = (size_t)((a.n_hyp + 63) / 64);
     unsigned long long key = ~0ull;
     if (!staged) {  // few hypotheses: every one is scored completely here, the block's best goes straight to the pair's minimum
-        typedef const __attribute__((address_space(4))) double* cdp;
-        const cdp pts = (cdp)(uintptr_t)xn;
-        double cost = 0.0;
-        if (valid) {
-#pragma unroll 4
-            for (int i = 0; i < m; i++) {
-                double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
-                cost += fmin(err, thr2);
-            }
-        }
+        const double cost = valid ? tv_cost_lane(E, xn, m, thr2) : 0.0;
         if (valid && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)(unsigned)h;
         const unsigned long long own = key;
         for (int o = 32; o > 0; o >>= 1) {
@@ -767,11 +781,14 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_tasks(TwoViewArgs a, TvWork w) 
     if (tid == 0) *w.n_tasks = total;
 }
 
-// Second stage: every lane sums one survivor's cost over all correspondences, sequentially in fp64 (the canonical sum the keys
-// are defined on); the wavefront's best goes to the pair's minimum and, with its matrix, to the slot k_tv_finish looks it up in.
-__global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
-    const int lane = threadIdx.x;
-    if ((int)blockIdx.x >= *w.n_tasks) return;
+// Second stage: the canonical cost of every survivor.  One workgroup per task of 64 survivors (one per lane), wavefront k sums part k;
+// the parts meet in LDS, wavefront 0 combines them and its best key goes to the pair's minimum and, with its matrix, to the slot
+// k_tv_finish looks it up in.  (Four wavefronts of different workgroups with a device-scope fence and a counter instead: 2.4x slower
+// - a release fence writes the L2 of the XCD back.)
+__global__ __launch_bounds__(64 * TV_PARTS) void k_tv_score(TwoViewArgs a, TvWork w) {
+    __shared__ double s_part[TV_PARTS][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if ((int)blockIdx.x >= *w.n_tasks) return;  // block-uniform
     const int2 tk = w.task[blockIdx.x];
     const int pair = tk.x, t0 = tk.y * 64;
     const int total = w.n_alive[pair];
@@ -779,19 +796,18 @@ __global__ __launch_bounds__(64) void k_tv_score(TwoViewArgs a, TvWork w) {
     const double thr = tv_thr(a, w, pair);
     const double thr2 = thr * thr;
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
-    typedef const __attribute__((address_space(4))) double* cdp;
-    const cdp pts = (cdp)(uintptr_t)xn;
     const bool on = t0 + lane < total;
     const double* rec = w.surv + ((size_t)pair * a.n_hyp + (on ? t0 + lane : t0)) * TV_REC;
     double E[9];
     for (int j = 0; j < 9; j++) E[j] = rec[j];
-    double cost = 0.0;
+    const int q = tv_part_len(m);
+    s_part[part][lane] = tv_cost_part(E, xn, min(m, part * q), min(m, (part + 1) * q), thr2);
+    __syncthreads();
+    if (part != 0) return;
+    double P[TV_PARTS];
+    for (int k = 0; k < TV_PARTS; k++) P[k] = s_part[k][lane];
+    const double cost = tv_combine(P);
     const unsigned h = (unsigned)__double_as_longlong(rec[9]);
-#pragma unroll 4
-    for (int i = 0; i < m; i++) {
-        double err = sampson_fast(E, pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]);
-        cost += fmin(err, thr2);
-    }
     unsigned long long key = ~0ull;
     if (on && cost == cost) key = ((unsigned long long)__float_as_uint((float)cost) << 32) | (unsigned long long)h;
     const unsigned long long own = key;
@@ -1173,7 +1189,7 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged, first_num);
     if (staged) {
         hipLaunchKernelGGL(k_tv_tasks, dim3(1), dim3(TV_BLOCK), 0, c->stream, a, w);
-        hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64), 0, c->stream, a, w);
+        hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64 * TV_PARTS), 0, c->stream, a, w);
     }
     hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
     HIPCHK(c, hipGetLastError());
