@@ -688,7 +688,8 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, i
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_BUF_BYTES (37 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): 4 workgroups per CU
+#define SEL_BUF_BYTES (33 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): 4 workgroups per CU together
+                                   // with the 3.4 KB of Harris windows and the replay scratch (19 - 37 KB measured alike)
 #define SEL_MAXSTRIPS 256
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
@@ -726,6 +727,52 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
 }
 
 #define SEL_THREADS 256
+#define HG 8                       // lanes per keypoint in the Harris phase
+#define HG_GROUPS (SEL_THREADS / HG)
+
+// Harris response of one keypoint by a group of HG = 8 lanes (same integer sums as harris_response, hence the same float):
+// the 9x9 window is fetched as 9 rows x 3 aligned dwords (27 loads dealt over the 8 lanes: 12 cache-line accesses per keypoint;
+// one lane per keypoint reading single bytes touched 81 lines with 64 different keypoints per load instruction and made this
+// phase the longest of the selection), parked in a group-private LDS tile, and lane g < 7 takes column g - 3 of the 7x7 block
+// with the separable forms Ix = d[r-1] + 2 d[r] + d[r+1], d = right - left, and Iy = s[r+1] - s[r-1], s = left + 2 centre + right.
+__device__ __forceinline__ float harris_group(const uint8_t* img, int pitch, int x0, int y0, uint32_t* tile /* [27] */, int g) {
+    const int xa = (x0 - 4) & ~3, off = (x0 - 4) - xa;  // bytes off .. off + 8 of the 12 fetched per row
+    const uint8_t* base = img + (size_t)(y0 - 4) * pitch + xa;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = g + HG * k;
+        if (q < 27) { const int r = q / 3, dw = q - 3 * r; tile[q] = *(const uint32_t*)(base + r * pitch + 4 * dw); }
+    }
+    replay::wave_sync();  // the group's lanes sit in one wavefront: its LDS writes are visible to all of them
+    int a = 0, b = 0, c = 0;
+    if (g < 7) {
+        const uint8_t* col = (const uint8_t*)tile + off + 1 + g;  // centre column of this lane: window column 4 + (g - 3)
+        int d[9], sm[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int l = col[12 * r - 1], m = col[12 * r], rt = col[12 * r + 1];
+            d[r] = rt - l;
+            sm[r] = l + 2 * m + rt;
+        }
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            const int Ix = d[r - 1] + 2 * d[r] + d[r + 1], Iy = sm[r + 1] - sm[r - 1];
+            a += Ix * Ix; b += Iy * Iy; c += Ix * Iy;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < HG; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+    replay::wave_sync();  // the tile may be overwritten by the group's next keypoint
+    const float scale = 1.f / ((1 << 2) * 7 * 255.f);
+    const float scale_sq_sq = scale * scale * scale * scale;
+    float fa = (float)a, fb = (float)b, fc = (float)c;
+    float t1 = fa * fb;
+    float t2 = fc * fc;
+    float sx = fa + fb;
+    float t3 = 0.04f * sx;
+    float t4 = t3 * sx;
+    return ((t1 - t2) - t4) * scale_sq_sq;
+}
 
 // phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota) replay, write-out;
 // all by the whole workgroup
@@ -734,11 +781,22 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
                                               uint16_t* rpos, unsigned long long* bl, FinalKp* fin, int* fin_cnt_out,
                                               int* flags, replay::WgScratch* ws) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < N1; i += SEL_THREADS) {
-        uint32_t e = A[i];
-        int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
-        float r = harris_response(img, lv.pitch, x, y);
-        B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
+    __shared__ uint32_t s_hw[HG_GROUPS][27];
+    if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {  // block-uniform; a keypoint sits >= edge_threshold >= 4 columns inside its row
+        const int grp = tid / HG, g = tid % HG;
+        for (int i0 = 0; i0 < N1; i0 += HG_GROUPS) {  // block-uniform trip count (the shuffles want whole wavefronts)
+            const int i = min(i0 + grp, N1 - 1);
+            const uint32_t e = A[i];
+            const float r = harris_group(img, lv.pitch, e & 0xFFF, (e >> 12) & 0xFFF, s_hw[grp], g);
+            if (g == 0 && i0 + grp < N1) B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
+        }
+    } else {
+        for (int i = tid; i < N1; i += SEL_THREADS) {
+            uint32_t e = A[i];
+            int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
+            float r = harris_response(img, lv.pitch, x, y);
+            B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
+        }
     }
     __syncthreads();
     int N2 = replay::wg_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid, ws);
