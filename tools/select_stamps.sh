@@ -15,7 +15,7 @@ def rep(a, b):
     global s
     assert a in s, a
     s = s.replace(a, b, 1)
-rep("        B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);\n    }\n    __syncthreads();\n", "        B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);\n    }\n    __syncthreads();\n    unsigned long long TH = __builtin_amdgcn_s_memtime();\n")
+rep("    __syncthreads();\n    int N2 = replay::wg_retain_best<uint64_t>(B, N1, lv.quota,", "    __syncthreads();\n    unsigned long long TH = __builtin_amdgcn_s_memtime();\n    int N2 = replay::wg_retain_best<uint64_t>(B, N1, lv.quota,")
 rep("    if (N2 > lv.fin_cap) {\n        if (tid == 0) atomicOr(&flags[0], 1);", "    unsigned long long TR = __builtin_amdgcn_s_memtime();\n    if (blockIdx.x == 3 && tid == 0) printf(\"STAMP2 L=%d N1=%d N2=%d harris_end %llu retain2 %llu\\n\", (int)blockIdx.y, N1, N2, TH, TR - TH);\n    if (N2 > lv.fin_cap) {\n        if (tid == 0) atomicOr(&flags[0], 1);")
 rep("    const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;  // dispatch order: all frames of the finest level first\n", "    const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;\n    unsigned long long T0 = __builtin_amdgcn_s_memtime();\n")
 rep("    // pass 1: retainBest(2 * quota) on the FAST score\n", "    unsigned long long T1 = __builtin_amdgcn_s_memtime();\n")

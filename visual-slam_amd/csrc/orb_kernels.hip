@@ -735,14 +735,19 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
 // one lane per keypoint reading single bytes touched 81 lines with 64 different keypoints per load instruction and made this
 // phase the longest of the selection), parked in a group-private LDS tile, and lane g < 7 takes column g - 3 of the 7x7 block
 // with the separable forms Ix = d[r-1] + 2 d[r] + d[r+1], d = right - left, and Iy = s[r+1] - s[r-1], s = left + 2 centre + right.
-__device__ __forceinline__ float harris_group(const uint8_t* img, int pitch, int x0, int y0, uint32_t* tile /* [27] */, int g) {
-    const int xa = (x0 - 4) & ~3, off = (x0 - 4) - xa;  // bytes off .. off + 8 of the 12 fetched per row
-    const uint8_t* base = img + (size_t)(y0 - 4) * pitch + xa;
+__device__ __forceinline__ void harris_fetch(const uint8_t* img, int pitch, int x0, int y0, int g, uint32_t (&reg)[4]) {
+    const uint8_t* base = img + (size_t)(y0 - 4) * pitch + ((x0 - 4) & ~3);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int q = g + HG * k;
-        if (q < 27) { const int r = q / 3, dw = q - 3 * r; tile[q] = *(const uint32_t*)(base + r * pitch + 4 * dw); }
+        const int q = min(g + HG * k, 26), r = q / 3, dw = q - 3 * r;  // (dwords 27 .. 31 of the deal re-read the last one)
+        reg[k] = *(const uint32_t*)(base + r * pitch + 4 * dw);
     }
+}
+__device__ __forceinline__ float harris_group(const uint32_t (&reg)[4], int x0, uint32_t* tile /* [27] */, int g) {
+    const int off = (x0 - 4) & 3;  // bytes off .. off + 8 of the 12 fetched per row
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (g + HG * k < 27) tile[g + HG * k] = reg[k];
     replay::wave_sync();  // the group's lanes sit in one wavefront: its LDS writes are visible to all of them
     int a = 0, b = 0, c = 0;
     if (g < 7) {
@@ -784,11 +789,22 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
     __shared__ uint32_t s_hw[HG_GROUPS][27];
     if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {  // block-uniform; a keypoint sits >= edge_threshold >= 4 columns inside its row
         const int grp = tid / HG, g = tid % HG;
-        for (int i0 = 0; i0 < N1; i0 += HG_GROUPS) {  // block-uniform trip count (the shuffles want whole wavefronts)
-            const int i = min(i0 + grp, N1 - 1);
-            const uint32_t e = A[i];
-            const float r = harris_group(img, lv.pitch, e & 0xFFF, (e >> 12) & 0xFFF, s_hw[grp], g);
-            if (g == 0 && i0 + grp < N1) B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e & 0xFFFFFFu);
+        // HB keypoints per group and trip: all their window loads are issued before the first one is reduced - the phase is a
+        // chain of global-load latencies (1.5 us per keypoint when taken one at a time), not of work
+        constexpr int HB = 4;
+        for (int i0 = 0; i0 < N1; i0 += HG_GROUPS * HB) {  // block-uniform trip count (the shuffles want whole wavefronts)
+            uint32_t e[HB], reg[HB][4];
+#pragma unroll
+            for (int u = 0; u < HB; u++) {
+                e[u] = A[min(i0 + u * HG_GROUPS + grp, N1 - 1)];
+                harris_fetch(img, lv.pitch, e[u] & 0xFFF, (e[u] >> 12) & 0xFFF, g, reg[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < HB; u++) {
+                const int i = i0 + u * HG_GROUPS + grp;
+                const float r = harris_group(reg[u], e[u] & 0xFFF, s_hw[grp], g);
+                if (g == 0 && i < N1) B[i] = ((uint64_t)__float_as_uint(r) << 32) | (e[u] & 0xFFFFFFu);
+            }
         }
     } else {
         for (int i = tid; i < N1; i += SEL_THREADS) {
