@@ -870,12 +870,28 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     // gather the strip lists in raster order: one wavefront per strip, strips dealt round-robin to the 4 wavefronts
     const uint32_t* src = cand + (size_t)frame * P.cand_stride + lv.cand_off;
     {
-        const int lane = tid & 63;
-        for (int s = tid >> 6; s < lv.nstrips; s += SEL_THREADS / 64) {
-            int b = s_pref[s], n = s_pref[s + 1] - b;
-            const uint32_t* e = src + (size_t)s * lv.strip_cap;
-            if (a_lds) for (int i = lane; i < n; i += WAVE) s_A[b + i] = e[i];
-            else for (int i = lane; i < n; i += WAVE) gA[b + i] = e[i];
+        // four strips per wavefront and trip: their first 64 records each are fetched together (a strip list is a dependent
+        // round trip, and a level has up to 60 of them: 15 per wavefront one after the other were 12 us of the level-0 chain)
+        const int lane = tid & 63, wv = tid >> 6;
+        constexpr int NW = SEL_THREADS / 64, GU = 4;
+        for (int s0 = wv; s0 < lv.nstrips; s0 += NW * GU) {  // wave-uniform
+            uint32_t v[GU];
+            int b[GU], n[GU];
+#pragma unroll
+            for (int u = 0; u < GU; u++) {
+                const int st = min(s0 + u * NW, lv.nstrips - 1);
+                b[u] = s_pref[st];
+                n[u] = s0 + u * NW < lv.nstrips ? s_pref[st + 1] - b[u] : 0;
+                v[u] = lane < n[u] ? src[(size_t)st * lv.strip_cap + lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < GU; u++) {
+                if (lane < n[u]) { if (a_lds) s_A[b[u] + lane] = v[u]; else gA[b[u] + lane] = v[u]; }
+                if (n[u] > WAVE) {  // wave-uniform: the rest of a long strip list
+                    const uint32_t* e = src + (size_t)(s0 + u * NW) * lv.strip_cap;
+                    for (int i = WAVE + lane; i < n[u]; i += WAVE) { if (a_lds) s_A[b[u] + i] = e[i]; else gA[b[u] + i] = e[i]; }
+                }
+            }
         }
     }
     __syncthreads();
