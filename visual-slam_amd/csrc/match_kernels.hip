@@ -182,15 +182,24 @@ __global__ __launch_bounds__(ML_THREADS) void k_match_lds(const uint8_t* __restr
             }
         };
         // groups of two descriptors with one group of look-ahead: the broadcast reads of group g+1 are in flight while
-        // group g is folded (reads past the last descriptor stay inside the padded buffer and are never folded)
+        // group g is folded (reads past the last descriptor stay inside the padded buffer and are never folded).  Two groups
+        // per trip in two register sets that swap roles: rotating one set cost four 64-bit moves per group, 12 % of the loop.
         uint4 c0 = s[0], c1 = s[1], c2 = s[2], c3 = s[3];
         int j = 0;
-#pragma unroll 2
-        for (; j + 2 <= n; j += 2) {
-            const uint4 n0 = s[2 * j + 4], n1 = s[2 * j + 5], n2 = s[2 * j + 6], n3 = s[2 * j + 7];
+        for (; j + 4 <= n; j += 4) {
+            const uint4 e0 = s[2 * j + 4], e1 = s[2 * j + 5], e2 = s[2 * j + 6], e3 = s[2 * j + 7];
             fold(c0, c1, j0 + j);
             fold(c2, c3, j0 + j + 1);
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            c0 = s[2 * j + 8]; c1 = s[2 * j + 9]; c2 = s[2 * j + 10]; c3 = s[2 * j + 11];
+            fold(e0, e1, j0 + j + 2);
+            fold(e2, e3, j0 + j + 3);
+        }
+        if (j + 2 <= n) {
+            const uint4 e0 = s[2 * j + 4], e1 = s[2 * j + 5];
+            fold(c0, c1, j0 + j);
+            fold(c2, c3, j0 + j + 1);
+            c0 = e0; c1 = e1;
+            j += 2;
         }
         if (j < n) fold(c0, c1, j0 + j);
         if (more) s_t[(tile + 1) & 1][tid] = nxt;
