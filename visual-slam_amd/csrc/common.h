@@ -48,8 +48,11 @@ struct FinalKp {  // 8 bytes: survivor of both retainBest passes, level coordina
     float response;
 };
 
-struct ResizeTab {  // device arrays of one level's INTER_LINEAR_EXACT coefficients
-    int* xofs = nullptr; int* xc1 = nullptr; int* yofs = nullptr; int* yc1 = nullptr;
+struct ResizeTab {  // device arrays of one level's INTER_LINEAR_EXACT coefficients (one allocation, base = xpk)
+    // packed per output column / row, padded to a multiple of 64 entries with the last one: source offset (15 bits) |
+    // (right / lower neighbour offset - offset) << 15 | weight of that neighbour in 1/256 units << 16 (k_resize2)
+    uint32_t* xpk = nullptr; uint32_t* ypk = nullptr;
+    int* xofs = nullptr; int* xc1 = nullptr; int* yofs = nullptr; int* yc1 = nullptr;  // the same, unpacked (k_resize)
 };
 
 #define MO_NSTAGES 16
@@ -60,6 +63,7 @@ struct mo_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in
                                // matrix-core matcher, 2 "scalar" round-1 kernel (train descriptors through scalar loads)
+    bool resize_gather = false;  // VSLAM_AMD_RESIZE=gather: the round-1 LDS-gather resize kernel for every level (A/B timing)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_aux0 = nullptr, ev_aux1 = nullptr;

@@ -63,6 +63,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
     }
     if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
     if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] == '1';
+    if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipEventCreate(&c->ev_aux0);
@@ -80,7 +81,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
 static void free_plan_buffers(mo_ctx* c) {
     for (int L = 0; L < MO_MAX_LEVELS; L++) {
         ResizeTab& t = c->rtab[L];
-        if (t.xofs) hipFree(t.xofs);
+        if (t.xpk) hipFree(t.xpk);
         t = ResizeTab();
     }
     void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab, c->d_strip_tab, c->d_lv_tab};
@@ -302,11 +303,24 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         std::vector<int> xo, xc, yo, yc;
         linear_coeffs(P.lv[L - 1].w, P.lv[L].w, xo, xc);
         linear_coeffs(P.lv[L - 1].h, P.lv[L].h, yo, yc);
-        size_t n = (size_t)2 * P.lv[L].w + 2 * P.lv[L].h;
+        const int dw = P.lv[L].w, dh = P.lv[L].h, wp = (dw + 63) & ~63, hp = (dh + 63) & ~63;
+        auto pack = [](const std::vector<int>& o, const std::vector<int>& c1, int srcsize, int padded) {
+            std::vector<uint32_t> t((size_t)padded);
+            for (int i = 0; i < padded; i++) {
+                const int j = std::min(i, (int)o.size() - 1), o1 = std::min(o[j] + 1, srcsize - 1);
+                t[i] = (uint32_t)o[j] | ((uint32_t)(o1 - o[j]) << 15) | ((uint32_t)c1[j] << 16);
+            }
+            return t;
+        };
+        const std::vector<uint32_t> xp = pack(xo, xc, P.lv[L - 1].w, wp), yp = pack(yo, yc, P.lv[L - 1].h, hp);
+        size_t n = (size_t)wp + hp + 2 * dw + 2 * dh;
         int* d = nullptr;
         HIPCHK(c, hipMalloc((void**)&d, n * sizeof(int)));
         ResizeTab& t = c->rtab[L];
-        t.xofs = d; t.xc1 = d + P.lv[L].w; t.yofs = d + 2 * P.lv[L].w; t.yc1 = t.yofs + P.lv[L].h;
+        t.xpk = (uint32_t*)d; t.ypk = t.xpk + wp;
+        t.xofs = d + wp + hp; t.xc1 = t.xofs + dw; t.yofs = t.xc1 + dw; t.yc1 = t.yofs + dh;
+        HIPCHK(c, hipMemcpy(t.xpk, xp.data(), xp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(t.ypk, yp.data(), yp.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(t.xofs, xo.data(), xo.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(t.xc1, xc.data(), xc.size() * sizeof(int), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(t.yofs, yo.data(), yo.size() * sizeof(int), hipMemcpyHostToDevice));

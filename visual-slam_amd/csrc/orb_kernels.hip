@@ -53,6 +53,11 @@ int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, ui
 }
 
 // ------------------------------------------------------------------ resize --------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
+}
+
 #define RS_TW 64
 #define RS_TH 64
 #define RS_SRC_ROWS 136   // source rows a 64-row output tile can touch (scale <= 2) + 1
@@ -145,6 +150,101 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     }
 }
 
+
+// Default resize kernel (late round 2): the same INTER_LINEAR_EXACT arithmetic in two separable passes.  k_resize above
+// gathers four source BYTES from an LDS window per output pixel and interpolates the two source rows of every output row
+// separately (each source row twice over): its LDS pipe was 62 % busy, 45 % of that bank conflicts, next to a vector unit
+// at 58 % (profiles/r02_pmc_per_kernel.json).  Here
+//   pass 1: every source row of the tile is interpolated ONCE along x, straight from three aligned global dwords per
+//           thread (4 adjacent output columns need <= 8 consecutive source bytes at scale <= 2): two v_alignbyte put the
+//           window at byte 0, one v_perm per column picks the (left, right) pair as u16x2, one v_dot2_u32_u16 against
+//           (256 - c, c) gives the row interpolant (< 2^16); four of them -> one 8-byte LDS store
+//   pass 2: an output row reads the interpolants of its two source rows (two ds_read_b64 per 4 pixels), pairs them with
+//           v_perm and finishes with one v_dot2 per pixel whose accumulator carries the rounding constant.
+// Tables: one packed dword per output column / row (ResizeTab).  Needs 4-byte aligned source rows; k_resize stays as the
+// path for sources that are not (dense caller images whose width is not a multiple of 4).
+#define RS2_ROWS 136  // source rows a 64-row output tile can touch (scale <= 2) + 1
+#define RS2_UNR 5
+__global__ __launch_bounds__(256) void k_resize2(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
+                                                 uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
+                                                 const uint32_t* __restrict__ xpk, const uint32_t* __restrict__ ypk,
+                                                 uint32_t inv_per, uint32_t inv_gx) {
+    __shared__ __attribute__((aligned(16))) uint2 s_h[RS2_ROWS][16];  // [source row of the tile][column group]: 4 x u16
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if ((gridDim.z & 7) == 0) {  // XCD affinity (speed only), as in k_resize
+        const uint32_t per = gridDim.x * gridDim.y, lin = bx + gridDim.x * (by + gridDim.y * bz), n = lin >> 3;
+        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n, rem = n - q * per;
+        bz = (int)((lin & 7) + 8 * q);
+        by = (int)(inv_gx ? __umulhi(rem, inv_gx) : rem);
+        bx = (int)(rem - (uint32_t)by * gridDim.x);
+    }
+    const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
+    // source rows of the tile from two wave-uniform table reads
+    const uint32_t ey0 = ypk[ty0], ey1 = ypk[min(ty0 + RS_TH - 1, dh - 1)];
+    const int sy0 = (int)(ey0 & 0x7FFFu), sy1 = (int)(ey1 & 0x7FFFu) + (int)((ey1 >> 15) & 1u);
+    const int nrows = sy1 - sy0 + 1;
+    if (nrows > RS2_ROWS) return;  // scale factor > 2: not supported by this tile shape (host checks)
+    const int cg = tid & 15, rr = tid >> 4;
+    const uint4 xe = *(const uint4*)(xpk + tx0 + 4 * cg);  // the tables are padded to a multiple of 64 entries
+    uint32_t ye[RS_TH / 16];
+#pragma unroll
+    for (int half = 0; half < RS_TH / 16; half++) ye[half] = ypk[ty0 + rr + 16 * half];
+    const uint32_t xk[4] = {xe.x, xe.y, xe.z, xe.w};
+    const int ox0 = (int)(xk[0] & 0x7FFFu), ab = ox0 & ~3;
+    const uint32_t sh8 = (uint32_t)(ox0 & 3);
+    uint32_t sel[4], coef[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t a = (xk[k] & 0x7FFFu) - (uint32_t)ox0, b = a + ((xk[k] >> 15) & 1u), c1 = xk[k] >> 16;
+        sel[k] = a | (b << 16) | 0x0C000C00u;       // {byte a, 0, byte b, 0} of the realigned 8-byte window
+        coef[k] = (256u - c1) | (c1 << 16);
+    }
+    // dwords past the end of the row are never needed (every byte used lies left of sw <= spitch): clamp them into the row
+    const int o1 = min(ab + 4, spitch - 4), o2 = min(ab + 8, spitch - 4);
+    const uint8_t* s0 = src + (size_t)bz * src_fstride + (size_t)sy0 * spitch;
+    // RS2_UNR rows per thread and trip with ALL their loads issued before the first is used: at scale 1.2 a tile touches <= 78
+    // source rows = 5 rows per thread, so the kernel makes one global round trip instead of five dependent ones (its
+    // workgroups live a few microseconds; the chain of round trips, not the instruction count, is what bounds them)
+    for (int r0 = rr; r0 < nrows; r0 += 16 * RS2_UNR) {
+        uint32_t w[RS2_UNR][3];
+#pragma unroll
+        for (int i = 0; i < RS2_UNR; i++) {
+            const uint8_t* row = s0 + (uint32_t)(min(r0 + 16 * i, nrows - 1) * spitch);  // rows past the window re-read its last row
+            w[i][0] = *(const uint32_t*)(row + ab); w[i][1] = *(const uint32_t*)(row + o1); w[i][2] = *(const uint32_t*)(row + o2);
+        }
+#pragma unroll
+        for (int i = 0; i < RS2_UNR; i++) {
+            const int r = r0 + 16 * i;
+            if (r >= nrows) break;
+            const uint32_t u0 = __builtin_amdgcn_alignbyte(w[i][1], w[i][0], sh8), u1 = __builtin_amdgcn_alignbyte(w[i][2], w[i][1], sh8);
+            uint32_t hv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) hv[k] = udot2(__builtin_amdgcn_perm(u1, u0, sel[k]), coef[k], 0u);
+            s_h[r][cg] = make_uint2(hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16));
+        }
+    }
+    __syncthreads();
+    const int x = tx0 + 4 * cg;
+    if (x >= dw) return;
+#pragma unroll
+    for (int half = 0; half < RS_TH / 16; half++) {
+        const int y = ty0 + rr + 16 * half;
+        if (y >= dh) break;
+        const uint32_t e = ye[half], c1 = e >> 16, cy = (256u - c1) | (c1 << 16);
+        const int oy = (int)(e & 0x7FFFu) - sy0, oy1 = oy + (int)((e >> 15) & 1u);
+        const uint2 a = s_h[oy][cg], b = s_h[oy1][cg];
+        const uint32_t v0 = udot2(__builtin_amdgcn_perm(b.x, a.x, 0x05040100u), cy, 32768u);
+        const uint32_t v1 = udot2(__builtin_amdgcn_perm(b.x, a.x, 0x07060302u), cy, 32768u);
+        const uint32_t v2 = udot2(__builtin_amdgcn_perm(b.y, a.y, 0x05040100u), cy, 32768u);
+        const uint32_t v3 = udot2(__builtin_amdgcn_perm(b.y, a.y, 0x07060302u), cy, 32768u);
+        // (v + 32768) >> 16 < 256 is byte 2 of every sum
+        const uint32_t packed = __builtin_amdgcn_perm(v1, v0, 0x0C0C0602u) | (__builtin_amdgcn_perm(v3, v2, 0x0C0C0602u) << 16);
+        // dpitch is a multiple of 16 >= dw: the <= 3 bytes past dw land in row padding
+        *(uint32_t*)(dst + (size_t)bz * dst_fstride + (size_t)y * dpitch + x) = packed;
+    }
+}
+
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
     const Plan& P = c->plan;
     for (int L = 1; L < nlevels; L++) {
@@ -155,8 +255,13 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels)
         const ResizeTab& t = c->rtab[L];
         dim3 grid((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, batch);
         const uint32_t per = grid.x * grid.y, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u, inv_gx = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
-                           (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1, inv_per, inv_gx);
+        const bool al4 = ((((size_t)src) | sfs | (size_t)s.pitch) & 3) == 0 && s.pitch >= 12;
+        if (al4 && !c->resize_gather)
+            hipLaunchKernelGGL(k_resize2, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
+                               (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xpk, t.ypk, inv_per, inv_gx);
+        else
+            hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
+                               (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1, inv_per, inv_gx);
     }
     HIPCHK(c, hipGetLastError());
     return MO_OK;
@@ -171,10 +276,6 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels)
 #define BT_PW (BT_W + 16)  // LDS pixel-tile pitch: 4 (aligned lead-in) + BT_W + 3 halo, rounded to a multiple of 16
 #define BT_ROWS (BT_H + 6)
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t udot2(uint32_t a, uint32_t b, uint32_t c) {
-    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b), c, false);
-}
 
 // {sat_u8(a >> 16), sat_u8(b >> 16)} in bits 0-7 and 8-15 (a, b < 2^31): five slow-class instructions pack four outputs instead
 // of a shift, a min and a shift-or each
