@@ -71,4 +71,10 @@ a = timed(lambda: extract(ca, kps2, desc2, cnt2))
 b = timed(lambda: match(cb))
 both = timed(lambda: (extract(ca, kps2, desc2, cnt2), match(cb)))
 print("extract alone %.3f ms, match alone %.3f ms, serial sum %.3f ms, both streams %.3f ms" % (a, b, a + b, both))
+# the matcher started together with the extraction only meets its vector-bound head (pyramid, FAST, blur); two and three
+# back-to-back match calls reach into the latency-bound tail (selection, describe)
+for n in (2, 3):
+    bn = timed(lambda: [match(cb) for _ in range(n)])
+    both = timed(lambda: (extract(ca, kps2, desc2, cnt2), [match(cb) for _ in range(n)]))
+    print("extract + %d x match: serial sum %.3f ms, both streams %.3f ms" % (n, a + bn, both))
 ca.close(); cb.close()

@@ -48,7 +48,7 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
         HIPCHK(c, hipStreamWaitEvent(aux, c->ev_fork, 0));
         c->stream = aux;
         if (c->timing) hipEventRecord(c->ev_aux0, aux);
-        rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels);
+        rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3);
         if (c->timing) hipEventRecord(c->ev_aux1, aux);
         hipEventRecord(c->ev_join, aux);
         c->stream = main_s;
@@ -185,7 +185,7 @@ extern "C" int mo_orb_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* 
     HIPCHK(c, hipMemcpyAsync(d_k, kk.data(), kb, hipMemcpyHostToDevice, c->stream));
     mo_stage_begin(c);
     if ((rc = orb_launch_pyramid(c, d_gray, 1, nlevels))) return rc;
-    if ((rc = orb_launch_blur(c, d_gray, 1, nlevels))) return rc;
+    if ((rc = orb_launch_blur(c, d_gray, 1, nlevels, 0))) return rc;
     if ((rc = orb_launch_describe_given(c, d_gray, d_k, n, d_d))) return rc;
     mo_stage_mark(c, "compute");
     HIPCHK(c, hipMemcpyAsync(desc, d_d, (size_t)n * 32, hipMemcpyDeviceToHost, c->stream));
@@ -638,7 +638,7 @@ extern "C" int mo_dbg_pyramid_level(mo_ctx* c, const mo_orb_params* p, const uin
     const LevelInfo& v = c->plan.lv[level];
     *lw = v.w; *lh = v.h;
     if (blurred) {
-        if ((rc = orb_launch_blur(c, d_gray, 1, c->plan.nlevels))) return rc;
+        if ((rc = orb_launch_blur(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
         HIPCHK(c, hipMemcpy2DAsync(out, v.w, c->d_blur + v.boff, v.bpitch, v.w, v.h, hipMemcpyDeviceToHost, c->stream));
     } else {
         const uint8_t* src = level == 0 ? d_gray : c->d_pyr + v.off;

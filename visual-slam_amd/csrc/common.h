@@ -64,6 +64,7 @@ struct mo_ctx {
     int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in
                                // matrix-core matcher, 2 "scalar" round-1 kernel (train descriptors through scalar loads)
     bool resize_gather = false;  // VSLAM_AMD_RESIZE=gather: the round-1 LDS-gather resize kernel for every level (A/B timing)
+    bool blur_full = false;      // VSLAM_AMD_BLUR=full: the pipeline blurs whole levels (A/B timing)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_aux0 = nullptr, ev_aux1 = nullptr;
@@ -88,8 +89,9 @@ struct mo_ctx {
     size_t scratch_stride = 0;     // u64 entries per frame of overflow scratch
     FinalKp* d_fin = nullptr;      // [batch][fin_stride]
     int* d_fin_cnt = nullptr;      // [batch][MO_MAX_LEVELS]
-    uint32_t* d_tile_tab = nullptr; int n_tile_tab = 0;    // blur: tile -> level | tile column << 8 | tile row << 20 (built with the plan)
-    int tile_cum[MO_MAX_LEVELS + 1] = {};                  // tiles of levels < L (the table is level-major: a prefix blurs the first levels)
+    uint32_t* d_tile_tab[2] = {nullptr, nullptr};          // blur: tile -> level | tile column << 8 | tile row << 20 (built with the plan); [0]: whole levels, [1]: without the margin tile_margin
+    int tile_cum[2][MO_MAX_LEVELS + 1] = {};               // tiles of levels < L (the tables are level-major: a prefix blurs the first levels)
+    int tile_margin = 0;
     uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
     int* d_lv_tab = nullptr;       // k_describe: per-level geometry table (built with the plan)
     int* d_flags = nullptr;        // [4] error flags raised by kernels
@@ -144,7 +146,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch);
 // kernel launchers (orb_kernels.hip)
 int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray);
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
-int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
+int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
 int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,

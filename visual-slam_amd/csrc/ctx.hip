@@ -64,6 +64,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
     if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
     if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] == '1';
     if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
+    if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipEventCreate(&c->ev_aux0);
@@ -84,10 +85,10 @@ static void free_plan_buffers(mo_ctx* c) {
         if (t.xpk) hipFree(t.xpk);
         t = ResizeTab();
     }
-    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab, c->d_strip_tab, c->d_lv_tab};
+    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab[0], c->d_tile_tab[1], c->d_strip_tab, c->d_lv_tab};
     c->d_lv_tab = nullptr;
     for (void* b : bufs) if (b) hipFree(b);
-    c->d_tile_tab = c->d_strip_tab = nullptr; c->n_tile_tab = c->n_strip_tab = 0;
+    c->d_tile_tab[0] = c->d_tile_tab[1] = nullptr; c->d_strip_tab = nullptr; c->n_strip_tab = 0;
     c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_strip_cnt = nullptr; c->d_scratch = nullptr;
     c->d_fin = nullptr; c->d_fin_cnt = nullptr;
     c->batch_alloc = 0;

@@ -290,7 +290,7 @@ __device__ __forceinline__ uint32_t hi16_pair_sat_u8(uint32_t a, uint32_t b) {
 // aligned dwords with v_alignbyte.  The u16 row sums of tile rows 2p and 2p+1 are stored interleaved in one dword per
 // column, so the column pass is four v_dot2_u32_u16 per output (tap pairs shifted by one row for odd output rows).
 // Interior tiles are staged with aligned dword loads; tiles touching the level border index with REFLECT_101.
-__global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
+__global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per, int org,
                                               const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               uint8_t* __restrict__ blur) {
     __shared__ __attribute__((aligned(16))) uint8_t s_px[BT_ROWS * BT_PW];
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
     const uint32_t te = tile_tab[tile];
     const int L = te & 0xFF;
     const LevelInfo lv = P.lv[L];
-    const int tx0 = (int)((te >> 8) & 0xFFF) * BT_W, ty0 = (int)(te >> 20) * BT_H;
+    const int tx0 = org + (int)((te >> 8) & 0xFFF) * BT_W, ty0 = org + (int)(te >> 20) * BT_H;  // org: margin the tiling skips
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const int tid = threadIdx.x;
     // s_px column c holds level column tx0 - 4 + c  (c = 1 .. BT_W + 6 are used).  Rows are reflected per tile row
@@ -404,24 +404,32 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
     }
 }
 
-int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
+// margin: the tiling covers [margin, w - margin) x [margin, h - margin) of every level.  The detector's keypoints lie at least
+// edge_threshold from the border and rBRIEF samples within 19 px of them, so the pipeline passes (edge_threshold - 19) & ~3
+// (12 at the default 31: 255 instead of 286 tiles per 640x480 frame); compute() with caller keypoints and the level probes
+// pass 0 (a caller's keypoint on a coarse octave may sample anywhere).
+int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin) {
     const Plan& P = c->plan;
     if (nlevels < 1 || nlevels > P.nlevels) return mo_fail(c, MO_ERR_ARG, "blur: level count outside the plan");
-    if (!c->d_tile_tab) {  // (re)built with the plan: free_plan_buffers drops it
+    const int slot = margin > 0 ? 1 : 0;
+    if (slot && c->tile_margin != margin && c->d_tile_tab[1]) { hipFree(c->d_tile_tab[1]); c->d_tile_tab[1] = nullptr; }
+    if (!c->d_tile_tab[slot]) {  // (re)built with the plan: free_plan_buffers drops it
         std::vector<uint32_t> tab;
         for (int L = 0; L < P.nlevels; L++) {
-            const int tx = (P.lv[L].w + BT_W - 1) / BT_W, ty = (P.lv[L].h + BT_H - 1) / BT_H;
-            c->tile_cum[L] = (int)tab.size();
+            const int cw = std::max(P.lv[L].w - 2 * margin, 1), chh = std::max(P.lv[L].h - 2 * margin, 1);
+            const int tx = (cw + BT_W - 1) / BT_W, ty = (chh + BT_H - 1) / BT_H;
+            c->tile_cum[slot][L] = (int)tab.size();
             for (int y = 0; y < ty; y++)
                 for (int x = 0; x < tx; x++) tab.push_back((uint32_t)L | ((uint32_t)x << 8) | ((uint32_t)y << 20));
         }
-        c->tile_cum[P.nlevels] = (int)tab.size();
-        HIPCHK(c, hipMalloc((void**)&c->d_tile_tab, tab.size() * sizeof(uint32_t)));
-        HIPCHK(c, hipMemcpy(c->d_tile_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        c->n_tile_tab = (int)tab.size();
+        c->tile_cum[slot][P.nlevels] = (int)tab.size();
+        HIPCHK(c, hipMalloc((void**)&c->d_tile_tab[slot], tab.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(c->d_tile_tab[slot], tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (slot) c->tile_margin = margin;
     }
-    const uint32_t per = (uint32_t)c->tile_cum[nlevels], inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;  // first nlevels levels
-    hipLaunchKernelGGL(k_blur, dim3(per, batch), dim3(256), 0, c->stream, P, c->d_tile_tab, inv_per, d_gray, c->d_pyr, c->d_blur);
+    const uint32_t per = (uint32_t)c->tile_cum[slot][nlevels], inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u;  // first nlevels levels
+    hipLaunchKernelGGL(k_blur, dim3(per, batch), dim3(256), 0, c->stream, P, c->d_tile_tab[slot], inv_per, margin, d_gray, c->d_pyr,
+                       c->d_blur);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
