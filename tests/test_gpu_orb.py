@@ -160,6 +160,30 @@ def test_batch_equals_single(ctx):
         assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1)
 
 
+@pytest.mark.parametrize("size", [(640, 480), (478, 850), (333, 257)])
+def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
+    """The pipeline leaves the outer 8 px of pyramid levels 1.. and the outer 12 px of the blurred levels unwritten (nothing it
+    computes reads them).  With the buffers poisoned by two different bytes before every extraction the output must still be the
+    oracle's, bit for bit - keypoints, angles and descriptors."""
+    import vslam_amd as V
+    img = synthetic_frame(321, size[0], size[1])
+    p, o = _prm(V, O, 0, nfeatures=2000, fast_threshold=7)
+    O.lib().orc_set_variant(0, 0)
+    ek, ed = O.detect_and_compute(img, o)
+    for poison in ("0", "255", "90"):
+        monkeypatch.setenv("VSLAM_AMD_POISON", poison)
+        c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=2)
+        try:
+            for _ in range(2):
+                (k, d), = c.orb_detect_compute(img, p)
+                for f in ("x", "y", "angle", "response", "octave"):
+                    assert np.array_equal(k[f], ek[f]), (poison, f)
+                assert np.array_equal(d, ed), poison
+        finally:
+            c.close()
+    O.lib().orc_set_variant(1, 0)
+
+
 def test_compute_given_keypoints(ctx, O):
     """orb.compute at caller keypoints: border drop, angle as supplied (-1), octave honoured, unsorted regroup."""
     import vslam_amd as V

@@ -37,8 +37,14 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     if (cap < 1) return mo_fail(c, MO_ERR_ARG, "cap must be >= 1");
     // host calls check the flags themselves before they return; mo_dev_* calls accumulate them until mo_dev_status
     if (host_call) HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    if (c->poison >= 0) {  // VSLAM_AMD_POISON=<byte> (tests): whatever the margins skip must never reach a result
+        HIPCHK(c, hipMemsetAsync(c->d_pyr, c->poison, (size_t)c->batch_alloc * c->plan.pyr_stride, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_blur, c->poison, (size_t)c->batch_alloc * c->plan.blur_stride, c->stream));
+    }
     mo_stage_begin(c);
-    if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels))) return rc;
+    // margins of the levels nothing in this pipeline reads (see orb_launch_blur / orb_launch_pyramid)
+    const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
+    if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels, pyr_margin))) return rc;
     mo_stage_mark(c, "pyramid");
     // the Gaussian blur only depends on the pyramid: it runs on the aux stream beside FAST + selection
     if (d_desc) {
@@ -48,7 +54,7 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
         HIPCHK(c, hipStreamWaitEvent(aux, c->ev_fork, 0));
         c->stream = aux;
         if (c->timing) hipEventRecord(c->ev_aux0, aux);
-        rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3);
+        rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin);
         if (c->timing) hipEventRecord(c->ev_aux1, aux);
         hipEventRecord(c->ev_join, aux);
         c->stream = main_s;
@@ -184,7 +190,7 @@ extern "C" int mo_orb_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* 
     uint8_t* d_d = (uint8_t*)c->d_tmp + kb;
     HIPCHK(c, hipMemcpyAsync(d_k, kk.data(), kb, hipMemcpyHostToDevice, c->stream));
     mo_stage_begin(c);
-    if ((rc = orb_launch_pyramid(c, d_gray, 1, nlevels))) return rc;
+    if ((rc = orb_launch_pyramid(c, d_gray, 1, nlevels, 0))) return rc;
     if ((rc = orb_launch_blur(c, d_gray, 1, nlevels, 0))) return rc;
     if ((rc = orb_launch_describe_given(c, d_gray, d_k, n, d_d))) return rc;
     mo_stage_mark(c, "compute");
@@ -634,7 +640,7 @@ extern "C" int mo_dbg_pyramid_level(mo_ctx* c, const mo_orb_params* p, const uin
     if (level < 0 || level >= c->plan.nlevels) return mo_fail(c, MO_ERR_ARG, "level out of range");
     const uint8_t* d_gray = nullptr;
     if ((rc = stage_images(c, gray, w, h, w, 1, 1, &d_gray))) return rc;
-    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels))) return rc;
+    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
     const LevelInfo& v = c->plan.lv[level];
     *lw = v.w; *lh = v.h;
     if (blurred) {
@@ -657,7 +663,7 @@ extern "C" int mo_dbg_fast_level(mo_ctx* c, const mo_orb_params* p, const uint8_
     if (level < 0 || level >= c->plan.nlevels) return mo_fail(c, MO_ERR_ARG, "level out of range");
     const uint8_t* d_gray = nullptr;
     if ((rc = stage_images(c, gray, w, h, w, 1, 1, &d_gray))) return rc;
-    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels))) return rc;
+    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
     if ((rc = orb_launch_fast(c, d_gray, 1))) return rc;
     const LevelInfo& v = c->plan.lv[level];
     std::vector<int> cnt(std::max(v.nstrips, 1));

@@ -64,6 +64,7 @@ struct mo_ctx {
     int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in
                                // matrix-core matcher, 2 "scalar" round-1 kernel (train descriptors through scalar loads)
     bool resize_gather = false;  // VSLAM_AMD_RESIZE=gather: the round-1 LDS-gather resize kernel for every level (A/B timing)
+    int poison = -1;             // VSLAM_AMD_POISON=<0..255>: fill the pyramid buffers with that byte before every extraction (tests)
     bool blur_full = false;      // VSLAM_AMD_BLUR=full: the pipeline blurs whole levels (A/B timing)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
@@ -145,7 +146,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch);
 
 // kernel launchers (orb_kernels.hip)
 int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray);
-int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels);
+int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
 int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
 int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);

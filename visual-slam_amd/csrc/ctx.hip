@@ -65,6 +65,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
     if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] == '1';
     if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
     if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
+    if (const char* e = getenv("VSLAM_AMD_POISON")) c->poison = atoi(e) & 255;
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipEventCreate(&c->ev_aux0);
@@ -304,7 +305,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         std::vector<int> xo, xc, yo, yc;
         linear_coeffs(P.lv[L - 1].w, P.lv[L].w, xo, xc);
         linear_coeffs(P.lv[L - 1].h, P.lv[L].h, yo, yc);
-        const int dw = P.lv[L].w, dh = P.lv[L].h, wp = (dw + 63) & ~63, hp = (dh + 63) & ~63;
+        const int dw = P.lv[L].w, dh = P.lv[L].h, wp = ((dw + 63) & ~63) + 64, hp = ((dh + 63) & ~63) + 64;  // + 64: the tiling may start at a margin
         auto pack = [](const std::vector<int>& o, const std::vector<int>& c1, int srcsize, int padded) {
             std::vector<uint32_t> t((size_t)padded);
             for (int i = 0; i < padded; i++) {

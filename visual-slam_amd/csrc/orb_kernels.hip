@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
                                                 uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
                                                 const int* __restrict__ xofs, const int* __restrict__ xc1,
                                                 const int* __restrict__ yofs, const int* __restrict__ yc1,
-                                                uint32_t inv_per, uint32_t inv_gx) {
+                                                uint32_t inv_per, uint32_t inv_gx, int org) {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_SRC_ROWS * RS_SRC_PITCH];
     __shared__ int s_xo[RS_TW], s_xc[RS_TW], s_yo[RS_TH], s_yc[RS_TH];
     const int tid = threadIdx.x;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
         by = (int)(inv_gx ? __umulhi(rem, inv_gx) : rem);
         bx = (int)(rem - (uint32_t)by * gridDim.x);
     }
-    const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
+    const int tx0 = org + bx * RS_TW, ty0 = org + by * RS_TH;  // org: margin of the level nothing reads (orb_launch_pyramid)
     const uint8_t* s = src + (size_t)bz * src_fstride;
     // source window of the tile from four wave-uniform (scalar) table reads, so that the coefficient tables and the
     // source pixels are fetched in the same round trip and one barrier covers both
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
 __global__ __launch_bounds__(256) void k_resize2(const uint8_t* __restrict__ src, size_t src_fstride, int spitch, int sw, int sh,
                                                  uint8_t* __restrict__ dst, size_t dst_fstride, int dpitch, int dw, int dh,
                                                  const uint32_t* __restrict__ xpk, const uint32_t* __restrict__ ypk,
-                                                 uint32_t inv_per, uint32_t inv_gx) {
+                                                 uint32_t inv_per, uint32_t inv_gx, int org) {
     __shared__ __attribute__((aligned(16))) uint2 s_h[RS2_ROWS][16];  // [source row of the tile][column group]: 4 x u16
     const int tid = threadIdx.x;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_resize2(const uint8_t* __restrict__ src
         by = (int)(inv_gx ? __umulhi(rem, inv_gx) : rem);
         bx = (int)(rem - (uint32_t)by * gridDim.x);
     }
-    const int tx0 = bx * RS_TW, ty0 = by * RS_TH;
+    const int tx0 = org + bx * RS_TW, ty0 = org + by * RS_TH;  // org: margin of the level nothing reads (orb_launch_pyramid)
     // source rows of the tile from two wave-uniform table reads
     const uint32_t ey0 = ypk[ty0], ey1 = ypk[min(ty0 + RS_TH - 1, dh - 1)];
     const int sy0 = (int)(ey0 & 0x7FFFu), sy1 = (int)(ey1 & 0x7FFFu) + (int)((ey1 >> 15) & 1u);
@@ -245,7 +245,11 @@ __global__ __launch_bounds__(256) void k_resize2(const uint8_t* __restrict__ src
     }
 }
 
-int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels) {
+// margin: only [margin, w - margin) x [margin, h - margin) of levels 1.. is produced (a multiple of 4).  The pipeline passes
+// the blur's margin - 4 (8 at edge_threshold 31): FAST stages from column 16 / row 27, the Harris and orientation windows stay
+// 16 px inside, the blur tiling starts at 12 and reads from 8, and the next level's [8, ..) only needs this level's [9, ..).
+// compute() with caller keypoints and the probes pass 0.
+int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin) {
     const Plan& P = c->plan;
     for (int L = 1; L < nlevels; L++) {
         const LevelInfo& s = P.lv[L - 1];
@@ -253,15 +257,16 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels)
         const uint8_t* src = L == 1 ? d_gray : c->d_pyr + s.off;
         size_t sfs = L == 1 ? (size_t)P.w * P.h : (size_t)P.pyr_stride;
         const ResizeTab& t = c->rtab[L];
-        dim3 grid((d.w + RS_TW - 1) / RS_TW, (d.h + RS_TH - 1) / RS_TH, batch);
+        const int org = (d.w > 2 * margin + 8 && d.h > 2 * margin + 8) ? margin : 0;
+        dim3 grid((d.w - 2 * org + RS_TW - 1) / RS_TW, (d.h - 2 * org + RS_TH - 1) / RS_TH, batch);
         const uint32_t per = grid.x * grid.y, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u, inv_gx = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
         const bool al4 = ((((size_t)src) | sfs | (size_t)s.pitch) & 3) == 0 && s.pitch >= 12;
         if (al4 && !c->resize_gather)
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
-                               (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xpk, t.ypk, inv_per, inv_gx);
+                               (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xpk, t.ypk, inv_per, inv_gx, org);
         else
             hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
-                               (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1, inv_per, inv_gx);
+                               (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xofs, t.xc1, t.yofs, t.yc1, inv_per, inv_gx, org);
     }
     HIPCHK(c, hipGetLastError());
     return MO_OK;
