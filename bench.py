@@ -345,7 +345,7 @@ def main():
         valu = kf.get("valu_insts")    # SQ_INSTS_VALU per launch (wave instructions)
         valu_frac = valu * 2.0 / (crit_ms * 1e-3 * 2.4e9 * 1024) if valu else None  # 2 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz
         # the same accounting for every stage (stand-alone duration; counters summed over the stage's kernels and launches per step)
-        STAGE_KERNELS = {"pyramid": ["k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
+        STAGE_KERNELS = {"pyramid": ["k_resize2", "k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
                          "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_pair_frames", "k_match_lds"],
                          "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_tasks", "k_tv_score", "k_tv_finish"]}
         per_kernel = None

@@ -4,6 +4,7 @@
 #      and of the same command with the blur serialised               -> r02_kernel_stats_serial_blur.csv
 #   2. one SQ counter pass (blur serialised: stand-alone kernels)     -> r02_pmc_sq.csv
 #   3. FETCH_SIZE and WRITE_SIZE in SEPARATE passes (guide: TCC slots) -> r02_pmc_fetch.csv, r02_pmc_write.csv
+#      (+ one FETCH_SIZE pass with whole-level blur for the counter calibration)
 # then profiles/summarize_r02.py writes r02_pmc_per_kernel.json.  Copy gpurun_out/r02/* into profiles/ afterwards.
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -21,5 +22,8 @@ VSLAM_AMD_SERIAL_BLUR=1 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
   --kernel-trace -d $O/sq -o sq --output-format csv -- $B > /dev/null 2> $O/sq.err
 VSLAM_AMD_SERIAL_BLUR=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o fetch --output-format csv -- $B > /dev/null 2> $O/fetch.err
 VSLAM_AMD_SERIAL_BLUR=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o write --output-format csv -- $B > /dev/null 2> $O/write.err
+# FETCH_SIZE calibration: with VSLAM_AMD_BLUR=full k_blur reads every level completely (243.3 MB per launch, far beyond L2), a byte
+# count the counter can be checked against; the default build skips the level margins nothing reads
+VSLAM_AMD_SERIAL_BLUR=1 VSLAM_AMD_BLUR=full rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch_full -o fetch --output-format csv -- $B > /dev/null 2> $O/fetch_full.err
 python3 $R/profiles/summarize_r02.py $O
 ls -la $O

@@ -48,10 +48,12 @@ for k in sorted(sq):
          "lds_active_cycles": avg(sq[k]["SQ_LDS_IDX_ACTIVE"]), "busy_cycles_sum_over_32_se": avg(sq[k]["SQ_BUSY_CYCLES"]),
          "fetch_bytes": f, "write_bytes": w, "hbm_bytes": (2 * f + w) if f is not None and w is not None else None}
     out["kernels"][k] = e
-if "k_blur" in out["kernels"] and out["kernels"]["k_blur"]["fetch_bytes"]:
-    out["fetch_calibration"] = {"kernel": "k_blur", "must_read_bytes": BLUR_ALG_READ,
-                                "fetch_size_bytes": out["kernels"]["k_blur"]["fetch_bytes"],
-                                "ratio_must_read_over_fetch_size": BLUR_ALG_READ / out["kernels"]["k_blur"]["fetch_bytes"]}
+cal_path = os.path.join(D, "fetch_full", "fetch_counter_collection.csv")
+if os.path.exists(cal_path):  # pass with VSLAM_AMD_BLUR=full: k_blur reads every level completely
+    cal = load(cal_path, os.path.join(D, "r02_pmc_fetch_full_blur.csv"))
+    fb = avg(cal["k_blur"]["FETCH_SIZE"]) * 1024
+    out["fetch_calibration"] = {"kernel": "k_blur (VSLAM_AMD_BLUR=full pass)", "must_read_bytes": BLUR_ALG_READ, "fetch_size_bytes": fb,
+                                "ratio_must_read_over_fetch_size": BLUR_ALG_READ / fb}
 json.dump(out, open(os.path.join(D, "r02_pmc_per_kernel.json"), "w"), indent=1)
 for k, e in out["kernels"].items():
     print("%-14s valu %.3g salu %.3g lds %.3g  fetch %s MB write %s MB" % (

@@ -64,6 +64,7 @@ struct mo_ctx {
     int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in
                                // matrix-core matcher, 2 "scalar" round-1 kernel (train descriptors through scalar loads)
     bool resize_gather = false;  // VSLAM_AMD_RESIZE=gather: the round-1 LDS-gather resize kernel for every level (A/B timing)
+    int strip_rows = MO_STRIP_ROWS;  // rows per FAST strip (VSLAM_AMD_STRIP_ROWS: A/B timing)
     int poison = -1;             // VSLAM_AMD_POISON=<0..255>: fill the pyramid buffers with that byte before every extraction (tests)
     bool blur_full = false;      // VSLAM_AMD_BLUR=full: the pipeline blurs whole levels (A/B timing)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)

@@ -66,6 +66,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
     if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
     if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
     if (const char* e = getenv("VSLAM_AMD_POISON")) c->poison = atoi(e) & 255;
+    if (const char* e = getenv("VSLAM_AMD_STRIP_ROWS")) c->strip_rows = std::min(std::max(atoi(e), 2), 16);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipEventCreate(&c->ev_aux0);
@@ -276,7 +277,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         if (v.w <= 2 * et || v.h <= 2 * et) { v.bx0 = v.by0 = et; v.bw = v.bh = 0; }
         else { v.bx0 = et; v.by0 = et; v.bw = v.w - 2 * et; v.bh = v.h - 2 * et; }
         v.inv_bw = v.bw > 1 ? 0xFFFFFFFFu / (uint32_t)v.bw + 1u : 0u;
-        v.strip_rows = MO_STRIP_ROWS;
+        v.strip_rows = c->strip_rows;
         while (v.strip_rows > 1 && v.strip_rows * v.bw > 16384) v.strip_rows /= 2;
         if (v.bw > 16384) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide");
         v.nstrips = v.bh > 0 ? (v.bh + v.strip_rows - 1) / v.strip_rows : 0;
