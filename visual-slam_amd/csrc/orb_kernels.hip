@@ -32,6 +32,20 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     return p;
 }
 
+// XCD affinity (speed only, any mapping is correct): consecutive workgroup ids go round-robin to the 8 XCDs, each with its own
+// L2.  Workgroup `lin` of a launch of `batch` frames x `per` workgroups works on frame (lin mod 8) + 8 * ((lin / 8) / per), so that
+// all workgroups of a frame share one id residue; the last batch mod 8 frames (a sharded rank extracts a halo frame beyond its
+// multiple of 8) keep the plain frame-major mapping.  inv_per: the host's reciprocal of `per` (0 encodes per == 1); exact while
+// dividend * divisor < 2^32.
+__device__ __forceinline__ void xcd_map(uint32_t lin, uint32_t per, uint32_t inv_per, uint32_t batch, int& frame, int& item) {
+    const uint32_t b8 = batch & ~7u, cut = per * b8;
+    const bool head = lin < cut;
+    const uint32_t n = head ? lin >> 3 : lin - cut;
+    const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / per
+    item = (int)(n - q * per);
+    frame = (int)(head ? (lin & 7u) + 8u * q : b8 + q);
+}
+
 __device__ __forceinline__ const uint8_t* level_ptr(const Plan& P, int L, const uint8_t* gray, const uint8_t* pyr,
                                                     int frame) {
     return L == 0 ? gray + (size_t)frame * P.w * P.h : pyr + (size_t)frame * P.pyr_stride + P.lv[L].off;
@@ -75,13 +89,11 @@ __global__ __launch_bounds__(256) void k_resize(const uint8_t* __restrict__ src,
     __shared__ int s_xo[RS_TW], s_xc[RS_TW], s_yo[RS_TH], s_yc[RS_TH];
     const int tid = threadIdx.x;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if ((gridDim.z & 7) == 0) {  // XCD affinity (speed only): all tiles of a frame on one XCD (the level just written is in its L2)
-        // divisions by the host's reciprocals (0 encodes a divisor of 1); exact while dividend * divisor < 2^32
-        const uint32_t per = gridDim.x * gridDim.y, lin = bx + gridDim.x * (by + gridDim.y * bz), n = lin >> 3;
-        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n, rem = n - q * per;
-        bz = (int)((lin & 7) + 8 * q);
-        by = (int)(inv_gx ? __umulhi(rem, inv_gx) : rem);
-        bx = (int)(rem - (uint32_t)by * gridDim.x);
+    {  // XCD affinity (speed only): all tiles of a frame on one XCD (the level just written is in its L2)
+        int rem;
+        xcd_map(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * gridDim.y, inv_per, gridDim.z, bz, rem);
+        by = (int)(inv_gx ? __umulhi((uint32_t)rem, inv_gx) : (uint32_t)rem);
+        bx = rem - by * (int)gridDim.x;
     }
     const int tx0 = org + bx * RS_TW, ty0 = org + by * RS_TH;  // org: margin of the level nothing reads (orb_launch_pyramid)
     const uint8_t* s = src + (size_t)bz * src_fstride;
@@ -172,12 +184,11 @@ __global__ __launch_bounds__(256) void k_resize2(const uint8_t* __restrict__ src
     __shared__ __attribute__((aligned(16))) uint2 s_h[RS2_ROWS][16];  // [source row of the tile][column group]: 4 x u16
     const int tid = threadIdx.x;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if ((gridDim.z & 7) == 0) {  // XCD affinity (speed only), as in k_resize
-        const uint32_t per = gridDim.x * gridDim.y, lin = bx + gridDim.x * (by + gridDim.y * bz), n = lin >> 3;
-        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n, rem = n - q * per;
-        bz = (int)((lin & 7) + 8 * q);
-        by = (int)(inv_gx ? __umulhi(rem, inv_gx) : rem);
-        bx = (int)(rem - (uint32_t)by * gridDim.x);
+    {  // XCD affinity (speed only): all tiles of a frame on one XCD (the level just written is in its L2)
+        int rem;
+        xcd_map(bx + gridDim.x * (by + gridDim.y * bz), gridDim.x * gridDim.y, inv_per, gridDim.z, bz, rem);
+        by = (int)(inv_gx ? __umulhi((uint32_t)rem, inv_gx) : (uint32_t)rem);
+        bx = rem - by * (int)gridDim.x;
     }
     const int tx0 = org + bx * RS_TW, ty0 = org + by * RS_TH;  // org: margin of the level nothing reads (orb_launch_pyramid)
     // source rows of the tile from two wave-uniform table reads
@@ -301,12 +312,7 @@ __global__ __launch_bounds__(256) void k_blur(Plan P, const uint32_t* __restrict
     __shared__ __attribute__((aligned(16))) uint8_t s_px[BT_ROWS * BT_PW];
     __shared__ __attribute__((aligned(16))) uint32_t s_row[(BT_ROWS / 2) * BT_W];  // [row pair][column] = lo: even row, hi: odd
     int tile = blockIdx.x, frame = blockIdx.y;
-    if ((gridDim.y & 7) == 0) {  // XCD affinity (speed only): all tiles of a frame on one XCD, so halo re-reads hit its L2
-        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
-        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / gridDim.x by the host's reciprocal (0: one per frame)
-        frame = (int)((lin & 7) + 8 * q);
-        tile = (int)(n - q * gridDim.x);
-    }
+    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, tile);  // XCD affinity (speed only)
     // one wave-uniform table read instead of a level search and two divisions per workgroup (the scalar prologue was as long
     // as the vector body of these short-lived workgroups)
     const uint32_t te = tile_tab[tile];
@@ -517,12 +523,7 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
                                               uint32_t* __restrict__ cand, int* __restrict__ strip_cnt, int score_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int strip = blockIdx.x, frame = blockIdx.y;
-    if ((gridDim.y & 7) == 0) {  // XCD affinity (speed only): all strips of a frame on one XCD, so halo rows hit its L2
-        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
-        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / gridDim.x by the host's reciprocal (0: one per frame)
-        frame = (int)((lin & 7) + 8 * q);
-        strip = (int)(n - q * gridDim.x);
-    }
+    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, strip);  // XCD affinity (speed only)
     const uint32_t se = strip_tab[strip0 + strip];  // one wave-uniform table read instead of a level search (strip0: first strip of this launch's levels)
     const int L = se & 0xFF;
     const LevelInfo lv = P.lv[L];
@@ -1269,12 +1270,7 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
     // its own L2.  Re-indexing so that all workgroups of a frame share one id residue keeps the frame's two pyramids
     // (2 MB) in ONE L2 while its keypoints are described, instead of being fetched into eight.
     int frame = blockIdx.y, wg = blockIdx.x;
-    if ((gridDim.y & 7) == 0) {
-        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y, n = lin >> 3;
-        const uint32_t q = inv_per ? __umulhi(n, inv_per) : n;  // n / gridDim.x by the host's reciprocal (0: one per frame)
-        frame = (int)((lin & 7) + 8 * q);
-        wg = (int)(n - q * gridDim.x);
-    }
+    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, wg);  // XCD affinity (speed only)
     const int grp = threadIdx.x / DG, gl = threadIdx.x % DG;
     const int k = wg * DK_PER_WG + grp;
     // The kernel is bound by its chain of DEPENDENT memory round trips times the few keypoints a CU holds in flight (round 1: a
