@@ -160,6 +160,24 @@ def test_batch_equals_single(ctx):
         assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1)
 
 
+@pytest.mark.parametrize("nb", [9, 17, 23])
+def test_batches_of_8k_plus_r_frames_equal_single(nb):
+    """XCD-affine workgroup mapping (orb_kernels.hip xcd_map): the first 8 * (nb // 8) frames are dealt by id residue, the last
+    nb % 8 keep the plain mapping - a sharded rank with a halo frame runs exactly this shape.  Every frame of the batch must
+    equal its single-frame result."""
+    import vslam_amd as V
+    p = V.orb_params(nfeatures=800)
+    imgs = np.stack([synthetic_frame(500 + i) for i in range(nb)])
+    c = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
+    try:
+        res = c.orb_detect_compute(imgs, p)
+        for i in range(nb):
+            (k1, d1), = c.orb_detect_compute(imgs[i], p)
+            assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), i
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("size", [(640, 480), (478, 850), (333, 257)])
 def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     """The pipeline leaves the outer 8 px of pyramid levels 1.. and the outer 12 px of the blurred levels unwritten (nothing it
