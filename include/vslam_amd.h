@@ -227,6 +227,10 @@ int mo_dev_status(mo_ctx*, int32_t flags[4]);
 /* per-stage device time of the last mo_dev_* call, measured with hipEvents on the context stream.
  * names: NULL-terminated array of stage names owned by the library; ms [n] filled. Returns n stages. */
 int mo_stage_times(mo_ctx*, const char*** names, float* ms, int cap);
+/* The same for the call `back` calls ago (0 = the last one, at most MO_TIMING_SLOTS - 1 = 63): the library keeps a ring of event
+ * sets, one per call, so a caller can enqueue many calls back to back and read their stage times after a single synchronisation
+ * instead of waiting for every call's last event (bench.py's timed region). */
+int mo_stage_times_back(mo_ctx*, int back, const char*** names, float* ms, int cap);
 
 /* internal-stage probes used by the parity tests (device pipeline, host in/out) */
 int mo_dbg_pyramid_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level, int blurred,

@@ -202,6 +202,22 @@ def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     O.lib().orc_set_variant(1, 0)
 
 
+def test_stage_times_ring(ctx):
+    """mo_stage_times_back: one event set per call, readable after later calls (bench.py reads a whole timed region after ONE sync)."""
+    import vslam_amd as V
+    p = V.orb_params(nfeatures=500)
+    img = synthetic_frame(7)
+    ctx.orb_detect_compute(img, p)
+    ctx.match_knn2_ratio(np.zeros((4, 32), np.uint8), np.zeros((5, 32), np.uint8), 0.75)
+    last, before = ctx.stage_times(0), ctx.stage_times(1)
+    assert [n for n, _ in last] == ["match_knn2_ratio"]
+    assert [n for n, _ in before] == ["pyramid", "fast_nms", "select_harris", "blur", "angle_rbrief"]
+    assert all(ms >= 0.0 for _, ms in last + before)
+    assert ctx.stage_times() == last
+    with pytest.raises(V.NativeError):
+        ctx.stage_times(V.TIMING_SLOTS)
+
+
 def test_compute_given_keypoints(ctx, O):
     """orb.compute at caller keypoints: border drop, angle as supplied (-1), octave honoured, unsorted regroup."""
     import vslam_amd as V

@@ -53,9 +53,9 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
         hipStream_t aux = c->serial_blur ? main_s : c->aux_stream;  // serial_blur: diagnostics (stand-alone stage times)
         HIPCHK(c, hipStreamWaitEvent(aux, c->ev_fork, 0));
         c->stream = aux;
-        if (c->timing) hipEventRecord(c->ev_aux0, aux);
+        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux0, aux);
         rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin);
-        if (c->timing) hipEventRecord(c->ev_aux1, aux);
+        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux1, aux);
         hipEventRecord(c->ev_join, aux);
         c->stream = main_s;
         if (rc) return rc;
@@ -67,7 +67,7 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     if (d_desc) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         mo_stage_mark(c, "blur");  // time taken from the aux-stream events; on the main stream this is only the join
-        c->aux_stage = c->n_stages - 1;
+        c->tsets[c->tcur].aux_stage = c->tsets[c->tcur].n_stages - 1;
     }
     if ((rc = orb_launch_describe(c, d_gray, batch, d_kps, d_desc, cap, d_counts))) return rc;
     mo_stage_mark(c, "angle_rbrief");

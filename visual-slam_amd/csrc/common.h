@@ -56,6 +56,14 @@ struct ResizeTab {  // device arrays of one level's INTER_LINEAR_EXACT coefficie
 };
 
 #define MO_NSTAGES 16
+#define MO_TIMING_SLOTS 64
+
+struct TimingSet {
+    hipEvent_t ev[MO_NSTAGES + 1] = {};
+    hipEvent_t aux0 = nullptr, aux1 = nullptr;  // span of the stage that ran on the aux stream
+    const char* names[MO_NSTAGES + 1] = {};
+    int n_stages = 0, aux_stage = -1;            // aux_stage: stage slot whose time comes from (aux0, aux1)
+};
 
 struct mo_ctx {
     int device = 0;
@@ -69,8 +77,7 @@ struct mo_ctx {
     bool blur_full = false;      // VSLAM_AMD_BLUR=full: the pipeline blurs whole levels (A/B timing)
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_aux0 = nullptr, ev_aux1 = nullptr;
-    float aux_ms = -1.f; int aux_stage = -1;    // stage slot whose time comes from the aux-stream events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     // plan (rebuilt when w, h or the ORB parameters change)
@@ -112,10 +119,10 @@ struct mo_ctx {
     // RCCL communicator of the sharded batched mode (comm.hip); null until mo_comm_init
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
 
-    // stage timing
-    hipEvent_t ev[MO_NSTAGES + 1] = {};
-    const char* stage_names[MO_NSTAGES + 1] = {};
-    int n_stages = 0;
+    // stage timing: a ring of event sets, one per mo_* call (mo_stage_begin advances it), so that a caller can enqueue many calls
+    // back to back and read the per-stage times of the last MO_TIMING_SLOTS of them after ONE synchronisation (mo_stage_times_back)
+    TimingSet tsets[MO_TIMING_SLOTS];
+    int tcur = 0;
     bool timing = true;
 };
 

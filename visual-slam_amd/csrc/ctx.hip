@@ -69,9 +69,11 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
     if (const char* e = getenv("VSLAM_AMD_STRIP_ROWS")) c->strip_rows = std::min(std::max(atoi(e), 2), 16);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    hipEventCreate(&c->ev_aux0);
-    hipEventCreate(&c->ev_aux1);
-    for (int i = 0; i <= MO_NSTAGES; i++) hipEventCreate(&c->ev[i]);
+    for (TimingSet& t : c->tsets) {
+        hipEventCreate(&t.aux0);
+        hipEventCreate(&t.aux1);
+        for (int i = 0; i <= MO_NSTAGES; i++) hipEventCreate(&t.ev[i]);
+    }
     if (hipMalloc((void**)&c->d_flags, 4 * sizeof(int)) != hipSuccess) {
         g_create_err = "mo_create: hipMalloc failed";
         delete c;
@@ -106,8 +108,11 @@ extern "C" void mo_destroy(mo_ctx* c) {
     void* bufs[] = {c->d_in, c->d_gray, c->d_flags, c->d_kps, c->d_desc, c->d_counts, c->d_mq, c->d_mt,
                     c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp};
     for (void* b : bufs) if (b) hipFree(b);
-    for (int i = 0; i <= MO_NSTAGES; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    if (c->ev_fork) { hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); hipEventDestroy(c->ev_aux0); hipEventDestroy(c->ev_aux1); }
+    for (TimingSet& t : c->tsets) {
+        for (int i = 0; i <= MO_NSTAGES; i++) if (t.ev[i]) hipEventDestroy(t.ev[i]);
+        if (t.aux0) { hipEventDestroy(t.aux0); hipEventDestroy(t.aux1); }
+    }
+    if (c->ev_fork) { hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -128,33 +133,40 @@ extern "C" int mo_sync(mo_ctx* c) {
 }
 
 void mo_stage_begin(mo_ctx* c) {
-    c->n_stages = 0;
-    c->aux_stage = -1;
-    if (c->timing) hipEventRecord(c->ev[0], c->stream);
+    c->tcur = (c->tcur + 1) % MO_TIMING_SLOTS;
+    TimingSet& t = c->tsets[c->tcur];
+    t.n_stages = 0;
+    t.aux_stage = -1;
+    if (c->timing) hipEventRecord(t.ev[0], c->stream);
 }
 
 void mo_stage_mark(mo_ctx* c, const char* name) {
-    if (!c->timing || c->n_stages >= MO_NSTAGES) return;
-    c->stage_names[c->n_stages] = name;
-    c->n_stages++;
-    hipEventRecord(c->ev[c->n_stages], c->stream);
+    TimingSet& t = c->tsets[c->tcur];
+    if (!c->timing || t.n_stages >= MO_NSTAGES) return;
+    t.names[t.n_stages] = name;
+    t.n_stages++;
+    hipEventRecord(t.ev[t.n_stages], c->stream);
 }
 
-extern "C" int mo_stage_times(mo_ctx* c, const char*** names, float* ms, int cap) {
+extern "C" int mo_stage_times_back(mo_ctx* c, int back, const char*** names, float* ms, int cap) {
     if (!c) return MO_ERR_ARG;
-    if (c->n_stages == 0) return 0;
-    HIPCHK(c, hipEventSynchronize(c->ev[c->n_stages]));
-    int n = std::min(cap, c->n_stages);
+    if (back < 0 || back >= MO_TIMING_SLOTS) return mo_fail(c, MO_ERR_ARG, "mo_stage_times_back: back outside the ring of event sets");
+    TimingSet& t = c->tsets[((c->tcur - back) % MO_TIMING_SLOTS + MO_TIMING_SLOTS) % MO_TIMING_SLOTS];
+    if (t.n_stages == 0) return 0;
+    HIPCHK(c, hipEventSynchronize(t.ev[t.n_stages]));
+    int n = std::min(cap, t.n_stages);
     for (int i = 0; i < n; i++) {
-        float t = 0;
-        hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
-        if (i == c->aux_stage) hipEventElapsedTime(&t, c->ev_aux0, c->ev_aux1);  // stage that ran on the aux stream
-        ms[i] = t;
+        float v = 0;
+        hipEventElapsedTime(&v, t.ev[i], t.ev[i + 1]);
+        if (i == t.aux_stage) hipEventElapsedTime(&v, t.aux0, t.aux1);  // stage that ran on the aux stream
+        ms[i] = v;
     }
-    c->stage_names[c->n_stages] = nullptr;
-    if (names) *names = c->stage_names;
+    t.names[t.n_stages] = nullptr;
+    if (names) *names = t.names;
     return n;
 }
+
+extern "C" int mo_stage_times(mo_ctx* c, const char*** names, float* ms, int cap) { return mo_stage_times_back(c, 0, names, ms, cap); }
 
 // INTER_LINEAR_EXACT coefficient table of one axis (interpolationLinear<ufixedpoint16>::getCoeffs):
 // offset + the weight of the right/lower neighbour in 1/256 units (left weight = 256 - c1).

@@ -50,6 +50,7 @@ class BatchIO(C.Structure):
 
 
 MODE_INIT, MODE_TRACK = 0, 1
+TIMING_SLOTS = 64  # MO_TIMING_SLOTS of the library: event sets kept for Context.stage_times(back)
 
 
 # every symbol include/vslam_amd.h declares: name -> (restype, argtypes)
@@ -83,6 +84,7 @@ SIGNATURES = {
     "mo_comm_destroy": (_i, [_vp]),
     "mo_gather_map_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
+    "mo_stage_times_back": (_i, [_vp, _i, _vp, _vp, _i]),
     "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dbg_fast_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "mo_dbg_retain_best": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -212,10 +214,11 @@ class Context:
         self._check(self.lib.mo_gather_map_points(self.h, C.c_void_p(d_local_ptr), int(rows_local), int(rows_max), int(cap), int(root),
                                                   C.c_void_p(d_all_ptr) if d_all_ptr else None, C.c_void_p(d_rows_all_ptr)))
 
-    def stage_times(self):
+    def stage_times(self, back=0):
+        """(name, ms) per stage of the call `back` calls ago (0 = the last; the library keeps TIMING_SLOTS event sets)"""
         names = C.POINTER(C.c_char_p)()
         ms = (C.c_float * 32)()
-        n = self.lib.mo_stage_times(self.h, C.byref(names), ms, 32)
+        n = self.lib.mo_stage_times_back(self.h, back, C.byref(names), ms, 32)
         if n < 0:
             self._check(n)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
