@@ -598,11 +598,19 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
     int n_pairs = io->batch - 1;
     if (n_pairs < 1 || !io->d_match_idx) return MO_OK;
     if (!io->d_match_dist || !io->d_match_pass) return mo_fail(c, MO_ERR_ARG, "match outputs missing");
-    size_t need = (size_t)n_pairs * 2 * sizeof(int32_t);
-    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, need))) return rc;
-    int32_t* qf = (int32_t*)c->d_tmp;
-    int32_t* tf = qf + n_pairs;
-    hipLaunchKernelGGL(k_pair_frames, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, qf, tf, n_pairs);
+    // (query, train) frame of every pair: written once per batch size into a buffer of its own (it was a 5 us launch per call)
+    if (c->pair_frames_n < n_pairs) {
+        if (c->d_pair_frames) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_pair_frames)); c->d_pair_frames = nullptr; }
+        c->pair_frames_n = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_pair_frames, (size_t)n_pairs * 2 * sizeof(int32_t)));
+        hipLaunchKernelGGL(k_pair_frames, dim3((n_pairs + 255) / 256), dim3(256), 0, c->stream, c->d_pair_frames, c->d_pair_frames + n_pairs,
+                           n_pairs);
+        HIPCHK(c, hipGetLastError());
+        c->pair_frames_n = n_pairs;
+        c->pair_frames_split = n_pairs;
+    }
+    int32_t* qf = c->d_pair_frames;
+    int32_t* tf = qf + c->pair_frames_split;
     rc = match_launch_pairs(c, io->d_desc, io->d_desc, (size_t)io->cap * 32, (size_t)io->cap * 32, io->d_counts, qf, tf, 0, 0,
                             n_pairs, io->cap, io->ratio, io->d_match_idx, io->d_match_dist, io->d_match_pass);
     if (rc) return rc;
