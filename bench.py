@@ -270,7 +270,7 @@ def main():
     subs = [SubBatch(cuts[j], cuts[j + 1], stream=main if S == 1 else None) for j in range(S)]
     stage_acc = {}
 
-    def step():
+    def step_local():
         for sb in subs:
             if sb.stream is not main:
                 sb.stream.wait_stream(main)
@@ -278,6 +278,9 @@ def main():
         for sb in subs:
             if sb.stream is not main:
                 main.wait_stream(sb.stream)
+
+    def step():
+        step_local()
         if world > 1:  # final map-point gather (the only collective on the path)
             gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all)
 
@@ -286,7 +289,7 @@ def main():
     # steps ahead of the W warm-up steps puts the timed region on the steady-state clock whatever K and W are.
     t_pw = time.perf_counter()
     while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
-        step()
+        step_local()  # (no collective in here: a time-based loop runs a different number of trips on every rank)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -372,7 +375,8 @@ def main():
                          "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_tasks", "k_tv_score", "k_tv_finish"]}
         per_kernel = None
         if alone and pmc.get("batch_frames") == B:
-            per_kernel, steps_prof = {}, 7.0  # profiles/collect_r02.sh: 5 timed + 2 warm-up steps per pass
+            # steps per profiled pass = launches of a once-per-step kernel (prewarm + warm-up + timed steps of profiles/collect_r02.sh)
+            per_kernel, steps_prof = {}, float(pmc["kernels"].get("k_fast", {}).get("launches", 7.0))
             for st, names in STAGE_KERNELS.items():
                 ks = [pmc["kernels"][n] for n in names if n in pmc.get("kernels", {})]
                 if not ks or st not in alone:

@@ -108,3 +108,27 @@ def test_two_ranks_on_one_gpu_equal_one_process():
     assert (~np.isnan(ref[..., 0])).sum() > 1000
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))
     ctx.close()
+
+
+def test_bench_launch_contract_two_ranks_gloo():
+    """bench.py exactly as the driver starts it for N > 1 (torch.distributed.run, one rank per process), rehearsed with two gloo ranks
+    sharing this box's GPU: every rank must run the same number of collectives (a time-based untimed loop once did not and hung), rank 0
+    prints ONE JSON line with the contract's keys, and the batch of 8k + 1 frames a rank > 0 extracts goes through the XCD mapping."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo",
+           "--batch", "16", "--prewarm-ms", "30"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01  # whole-job frames / time
