@@ -178,6 +178,29 @@ def test_batches_of_8k_plus_r_frames_equal_single(nb):
         c.close()
 
 
+@pytest.mark.parametrize("edge,scale,nlev", [(19, 1.2, 8), (20, 1.2, 8), (48, 1.2, 8), (31, 1.5, 5), (40, 2.0, 4)])
+def test_level_margins_follow_the_edge_threshold(O, edge, scale, nlev, monkeypatch):
+    """Margins = f(edge_threshold): none at 19 - 22 (the descriptor radius), 28 / 24 px at 48; coarser scale factors move the source
+    window of the next level.  Poisoned buffers, output equal to the oracle's."""
+    import vslam_amd as V
+    img = synthetic_frame(99)
+    kw = dict(nfeatures=1500, fast_threshold=9, edge_threshold=edge, scale_factor=scale, nlevels=nlev)
+    p, o = _prm(V, O, 0, **kw)
+    O.lib().orc_set_variant(0, 0)
+    ek, ed = O.detect_and_compute(img, o)
+    assert len(ek) > 300
+    monkeypatch.setenv("VSLAM_AMD_POISON", "171")
+    c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+    try:
+        (k, d), = c.orb_detect_compute(img, p)
+        for f in ("x", "y", "angle", "response", "octave"):
+            assert np.array_equal(k[f], ek[f]), f
+        assert np.array_equal(d, ed)
+    finally:
+        c.close()
+        O.lib().orc_set_variant(1, 0)
+
+
 @pytest.mark.parametrize("size", [(640, 480), (478, 850), (333, 257)])
 def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     """The pipeline leaves the outer 8 px of pyramid levels 1.. and the outer 12 px of the blurred levels unwritten (nothing it
