@@ -111,6 +111,16 @@ static int reserve_out(mo_ctx* c, int batch, int cap) {
     return MO_OK;
 }
 
+// pinned host staging owned by the context (small host-API transfers: one async copy each way and one synchronisation instead of
+// a blocking round trip per pageable array)
+static int host_stage(mo_ctx* c, size_t bytes) {
+    if (c->h_stage_bytes >= bytes) return MO_OK;
+    if (c->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_bytes = 0; }
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault));
+    c->h_stage_bytes = bytes;
+    return MO_OK;
+}
+
 extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
                                      int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts) {
     if (!c) return MO_ERR_ARG;
@@ -122,6 +132,31 @@ extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const ui
     if ((rc = stage_images(c, img, w, h, stride, ch, batch, &d_gray))) return rc;
     if ((rc = reserve_out(c, batch, cap))) return rc;
     if ((rc = run_extract(c, p, d_gray, w, h, batch, c->d_kps, desc ? c->d_desc : nullptr, cap, c->d_counts, true))) return rc;
+    // Small results (the single-frame calls of the drop-in classes): flags, counts, keypoints and descriptors travel into ONE pinned
+    // staging buffer behind one synchronisation; copies into the caller's pageable arrays cost a blocking round trip each (four
+    // per call before: counts, flags, keypoints, descriptors).
+    const size_t n_rows = (size_t)batch * cap, o_cnt = 4 * sizeof(int), o_kps = (o_cnt + (size_t)batch * sizeof(int) + 15) & ~(size_t)15;
+    const size_t o_desc = o_kps + n_rows * sizeof(mo_keypoint), total = o_desc + (desc ? n_rows * 32 : 0);
+    if (total <= (size_t)2 << 20) {
+        if ((rc = host_stage(c, total))) return rc;
+        uint8_t* hs = c->h_stage;
+        HIPCHK(c, hipMemcpyAsync(hs, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hs + o_cnt, c->d_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hs + o_kps, c->d_kps, n_rows * sizeof(mo_keypoint), hipMemcpyDeviceToHost, c->stream));
+        if (desc) HIPCHK(c, hipMemcpyAsync(hs + o_desc, c->d_desc, n_rows * 32, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(counts, hs + o_cnt, (size_t)batch * sizeof(int));  // MO_ERR_CAPACITY: counts already holds the sizes a retry needs
+        const int fl = ((const int*)hs)[0];
+        if (fl & 1) return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)");
+        if (fl & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
+        for (int f = 0; f < batch; f++) {
+            const int n = std::min(counts[f], cap);
+            if (n <= 0) continue;
+            std::memcpy(kps + (size_t)f * cap, hs + o_kps + (size_t)f * cap * sizeof(mo_keypoint), (size_t)n * sizeof(mo_keypoint));
+            if (desc) std::memcpy(desc + (size_t)f * cap * 32, hs + o_desc + (size_t)f * cap * 32, (size_t)n * 32);
+        }
+        return MO_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(counts, c->d_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     rc = check_flags(c);  // MO_ERR_CAPACITY: counts already holds the sizes a retry needs
     if (rc) return rc;
@@ -302,13 +337,35 @@ extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const ui
         HIPCHK(c, hipMalloc((void**)&c->d_mpass, n));
         c->m_n = n;
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_mq, q, qb, hipMemcpyHostToDevice, c->stream));
-    if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, t, (size_t)batch * nt * 32, hipMemcpyHostToDevice, c->stream));
+    const size_t tbytes = (size_t)batch * nt * 32, o_t = (qb + 15) & ~(size_t)15, o_idx = (o_t + tbytes + 15) & ~(size_t)15;
+    const size_t o_dist = o_idx + n * 2 * sizeof(int32_t), o_pass = o_dist + n * 2 * sizeof(int32_t), total = o_pass + n;
+    const bool staged = total <= (size_t)2 << 20;  // the single-pair calls of the drop-in classes
+    if (staged) {
+        if ((rc = host_stage(c, total))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (the staging buffer of a previous call has been consumed)
+        std::memcpy(c->h_stage, q, qb);
+        if (nt > 0) std::memcpy(c->h_stage + o_t, t, tbytes);
+        HIPCHK(c, hipMemcpyAsync(c->d_mq, c->h_stage, qb, hipMemcpyHostToDevice, c->stream));
+        if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, c->h_stage + o_t, tbytes, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_mq, q, qb, hipMemcpyHostToDevice, c->stream));
+        if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, t, tbytes, hipMemcpyHostToDevice, c->stream));
+    }
     mo_stage_begin(c);
     rc = match_launch_pairs(c, c->d_mq, c->d_mt, (size_t)nq * 32, (size_t)nt * 32, nullptr, nullptr, nullptr, nq, nt, batch,
                             nq, ratio ? *ratio : -1.0, c->d_midx, c->d_mdist, c->d_mpass);
     if (rc) return rc;
     mo_stage_mark(c, "match_knn2_ratio");
+    if (staged) {
+        HIPCHK(c, hipMemcpyAsync(c->h_stage + o_idx, c->d_midx, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_stage + o_dist, c->d_mdist, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_stage + o_pass, c->d_mpass, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(train_idx, c->h_stage + o_idx, n * 2 * sizeof(int32_t));
+        std::memcpy(dist, c->h_stage + o_dist, n * 2 * sizeof(int32_t));
+        std::memcpy(pass, c->h_stage + o_pass, n);
+        return MO_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(train_idx, c->d_midx, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(dist, c->d_mdist, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(pass, c->d_mpass, n, hipMemcpyDeviceToHost, c->stream));

@@ -119,6 +119,7 @@ struct mo_ctx {
     // RCCL communicator of the sharded batched mode (comm.hip); null until mo_comm_init
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
 
+    uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned host staging of small host-API results
     int32_t* d_pair_frames = nullptr; int pair_frames_n = 0, pair_frames_split = 0;  // mo_dev_frontend_batch: qf[i] = i, tf[i] = i + 1
     // stage timing: a ring of event sets, one per mo_* call (mo_stage_begin advances it), so that a caller can enqueue many calls
     // back to back and read the per-stage times of the last MO_TIMING_SLOTS of them after ONE synchronisation (mo_stage_times_back)

@@ -112,6 +112,7 @@ extern "C" void mo_destroy(mo_ctx* c) {
     void* bufs[] = {c->d_in, c->d_gray, c->d_flags, c->d_kps, c->d_desc, c->d_counts, c->d_mq, c->d_mt,
                     c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp, c->d_pair_frames};
     for (void* b : bufs) if (b) hipFree(b);
+    if (c->h_stage) hipHostFree(c->h_stage);
     for (TimingSet& t : c->tsets) {
         for (int i = 0; i <= MO_NSTAGES; i++) if (t.ev[i]) hipEventDestroy(t.ev[i]);
         if (t.aux0) { hipEventDestroy(t.aux0); hipEventDestroy(t.aux1); }
