@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r02
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optin --no-extras"
+B="python3 $R/bench.py --steps 5 --warmup 2 --prewarm-ms 50 --no-cpu-baseline --no-optin --no-extras"
 rocprofv3 --kernel-trace --stats -d $O/stats -o r02 --output-format csv -- $B > $O/r02_bench_under_rocprof.json 2> $O/stats.err
 cp $O/stats/r02_kernel_stats.csv $O/r02_kernel_stats.csv
 # the same with the blur serialised: every kernel alone on the GPU - these averages are what bench.py's roofline.kernel_ms /
