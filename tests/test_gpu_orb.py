@@ -201,6 +201,29 @@ def test_level_margins_follow_the_edge_threshold(O, edge, scale, nlev, monkeypat
         O.lib().orc_set_variant(1, 0)
 
 
+def test_level_ratio_above_two_keeps_the_gather_resize(O):
+    """scale_factor 2.0 on a 666-px-wide frame: level 2 is 166 px wide from 333 (ratio 2.006), so four adjacent output columns can need
+    9 consecutive source bytes - more than k_resize2's 8-byte window; mo_build_plan detects it per level and that level is resized by
+    the gather kernel.  Pyramid levels and the final output must equal the oracle's."""
+    import vslam_amd as V
+    img = synthetic_frame(4242, 666, 500)
+    kw = dict(nfeatures=1200, fast_threshold=9, scale_factor=2.0, nlevels=4)
+    p, o = _prm(V, O, 0, **kw)
+    O.lib().orc_set_variant(0, 0)
+    c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=1)
+    try:
+        for L in range(4):
+            assert np.array_equal(c.dbg_pyramid_level(img, p, L), O.pyramid_level(img, o, L)), L
+        ek, ed = O.detect_and_compute(img, o)
+        (k, d), = c.orb_detect_compute(img, p)
+        for f in ("x", "y", "angle", "response", "octave"):
+            assert np.array_equal(k[f], ek[f]), f
+        assert np.array_equal(d, ed) and len(ek) > 300
+    finally:
+        c.close()
+        O.lib().orc_set_variant(1, 0)
+
+
 @pytest.mark.parametrize("size", [(640, 480), (478, 850), (333, 257)])
 def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     """The pipeline leaves the outer 8 px of pyramid levels 1.. and the outer 12 px of the blurred levels unwritten (nothing it

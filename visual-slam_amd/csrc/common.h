@@ -53,6 +53,7 @@ struct ResizeTab {  // device arrays of one level's INTER_LINEAR_EXACT coefficie
     // (right / lower neighbour offset - offset) << 15 | weight of that neighbour in 1/256 units << 16 (k_resize2)
     uint32_t* xpk = nullptr; uint32_t* ypk = nullptr;
     int* xofs = nullptr; int* xc1 = nullptr; int* yofs = nullptr; int* yc1 = nullptr;  // the same, unpacked (k_resize)
+    bool two_pass_ok = true;  // k_resize2's 8-byte source window holds every group of 4 output columns
 };
 
 #define MO_NSTAGES 16

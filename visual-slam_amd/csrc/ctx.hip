@@ -333,6 +333,15 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
             return t;
         };
         const std::vector<uint32_t> xp = pack(xo, xc, P.lv[L - 1].w, wp), yp = pack(yo, yc, P.lv[L - 1].h, hp);
+        // k_resize2 takes the source bytes of 4 adjacent output columns from ONE 8-byte window: right neighbour of the last
+        // column - offset of the first <= 7.  Always true below a level ratio of 2; rounded level widths can put the ratio a
+        // little above it at scale_factor 2 (333 -> 166), and such a level keeps the gather kernel
+        bool window_ok = true;
+        for (int x = 0; x < dw && window_ok; x++) {
+            const int xl = std::min(x + 3, dw - 1);
+            window_ok = std::min(xo[xl] + 1, P.lv[L - 1].w - 1) - xo[x] <= 7;
+        }
+        c->rtab[L].two_pass_ok = window_ok;
         size_t n = (size_t)wp + hp + 2 * dw + 2 * dh;
         int* d = nullptr;
         HIPCHK(c, hipMalloc((void**)&d, n * sizeof(int)));

@@ -272,7 +272,7 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels,
         dim3 grid((d.w - 2 * org + RS_TW - 1) / RS_TW, (d.h - 2 * org + RS_TH - 1) / RS_TH, batch);
         const uint32_t per = grid.x * grid.y, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u, inv_gx = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
         const bool al4 = ((((size_t)src) | sfs | (size_t)s.pitch) & 3) == 0 && s.pitch >= 12;
-        if (al4 && !c->resize_gather)
+        if (al4 && t.two_pass_ok && !c->resize_gather)
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
                                (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xpk, t.ypk, inv_per, inv_gx, org);
         else
