@@ -42,7 +42,18 @@ except Exception:
 def keypoints_from_array(arr):
     """structured mo_keypoint array -> tuple of KeyPoint objects (cv2 returns a tuple)"""
     # one bulk conversion to Python scalars (tolist) instead of seven numpy scalar reads per keypoint: 3 ms -> 0.7 ms for 2000
-    return tuple(KeyPoint(*t) for t in arr.tolist())
+    rows = arr.tolist()
+    if HAVE_CV2:
+        return tuple(KeyPoint(*t) for t in rows)
+    # the stand-in class: tolist() already yields Python floats / ints, so the slots are filled directly instead of through
+    # __init__'s seven conversions (another quarter of the time for 2000 keypoints)
+    new, out = object.__new__, []
+    append = out.append
+    for x, y, size, angle, response, octave, class_id in rows:
+        k = new(KeyPoint)
+        k.pt = (x, y); k.size = size; k.angle = angle; k.response = response; k.octave = octave; k.class_id = class_id
+        append(k)
+    return tuple(out)
 
 
 def keypoints_to_array(kps):
