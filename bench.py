@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches (HIP streams) per GPU")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed steps for this long ahead of the warm-up steps (clock ramp)")
+    ap.add_argument("--sync-gather", type=int, default=0, help="N > 1: 1 = blocking gather after every step instead of the overlapped one")
     ap.add_argument("--sync-steps", type=int, default=0, help="1: the host waits for every step before it enqueues the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra timing of the opt-in matrix-core matcher")
@@ -227,6 +228,7 @@ def main():
     prm = V.orb_params(nfeatures=NFEAT, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=7,
                        select_order=V.ORDER_LIBSTDCXX)
     pts = torch.zeros((B, CAP, 3), dtype=torch.float32, device=dev)  # rank 0 fills B-1 pairs, the others B
+    pts_alt = torch.zeros_like(pts) if world > 1 else pts            # N > 1: steps alternate between two buffers (see step())
     npts = torch.zeros(B, dtype=torch.int32, device=dev)
 
     class SubBatch:
@@ -285,10 +287,36 @@ def main():
             if sb.stream is not main:
                 main.wait_stream(sb.stream)
 
+    # N > 1: the gather of step i runs on RCCL's own stream beside the kernels of step i + 1 (rank 0 receives 7 x 12.6 MB per step at
+    # N = 8, ~0.3 ms of a 4.2 ms step if the next step waited for it).  Steps alternate between two map-point buffers; a buffer is
+    # handed to the pipeline again only after the gather that read it has been waited for (a stream-level wait under RCCL).
+    # --sync-gather 1: the plain blocking gather after every step.
+    pending = [None, None]
+    step_no = [0]
+
     def step():
+        k = step_no[0] & 1
+        step_no[0] += 1
+        if world == 1 or args.sync_gather:
+            step_local()
+            if world > 1:  # final map-point gather (the only collective on the path)
+                gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all)
+            return
+        if pending[k] is not None:
+            pending[k][1]()          # the gather that read this buffer two steps ago
+            pending[k] = None
+        buf = pts if k == 0 else pts_alt
+        for sb in subs:
+            sb.io.d_points = buf[sb.p0:].data_ptr()
         step_local()
-        if world > 1:  # final map-point gather (the only collective on the path)
-            gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all)
+        pending[k] = gather_map_points(buf if args.backend == "nccl" else buf.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all,
+                                       async_op=True)
+
+    def drain():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k][1]()
+                pending[k] = None
 
     # Clock ramp: after the idle seconds of frame generation and context creation the first ~100 ms of work run 3 % below the
     # steady-state rate (10 timed steps after 2 warm-up steps: 2.30 ms per step, 40 steps: 2.24 ms).  A fixed stretch of untimed
@@ -299,6 +327,7 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -313,6 +342,7 @@ def main():
         if args.sync_steps:
             for sb in subs:
                 sb.ctx.sync()
+    drain()  # (inside the timed region: every gather has completed before the clock stops)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -30,11 +30,19 @@ def _worker(rank, world, port, q):
     got = gather_map_points(pts, n_pairs, dst=0)
     # the caller-supplied pair counts (what bench.py passes) must give the same lists without the count exchange
     got2 = gather_map_points(pts, n_pairs, dst=0, pairs_per_rank=[shard(r, world, B)[2] for r in range(world)])
+    # the overlapped form bench.py uses for N > 1: two gathers in flight on two buffers, waited for in order
+    ppr = [shard(r, world, B)[2] for r in range(world)]
+    pts_b = pts.clone()
+    w1 = gather_map_points(pts, n_pairs, dst=0, pairs_per_rank=ppr, async_op=True)
+    w2 = gather_map_points(pts_b, n_pairs, dst=0, pairs_per_rank=ppr, async_op=True)
+    got3, got4 = w1[1](), w2[1]()
     if rank == 0:
         assert all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(got, got2)) and len(got) == len(got2)
+        for g in (got3, got4):
+            assert len(g) == len(got) and all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(got, g))
         q.put(torch.cat(got).numpy())
     else:
-        assert got is None and got2 is None
+        assert got is None and got2 is None and got3 is None and got4 is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -18,12 +18,13 @@ def shard(rank, world, frames_per_rank):
     return first, n, n - 1, first
 
 
-def gather_map_points(points, n_pairs, dst=0, group=None, pairs_per_rank=None):
+def gather_map_points(points, n_pairs, dst=0, group=None, pairs_per_rank=None, async_op=False):
     """points: [rows >= n_pairs, cap, 3] float tensor, NaN where a query keypoint produced no map point.
     Padded gather to `dst` (fixed-size collective: payload is MBs, latency-bound on xGMI).  On dst returns a list
     with one [n_pairs_r, cap, 3] tensor per rank in global pair order, elsewhere None.
     pairs_per_rank: the pair count of every rank when the caller knows it (contiguous sharding does: shard(r, ...)[2]);
-    without it the counts are exchanged with one extra all_gather and a host read per rank."""
+    without it the counts are exchanged with one extra all_gather and a host read per rank.
+    async_op: see below (world > 1 only; a world of one returns the synchronous result)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return [points[:n_pairs]]
@@ -33,6 +34,19 @@ def gather_map_points(points, n_pairs, dst=0, group=None, pairs_per_rank=None):
         metas = [torch.zeros_like(meta) for _ in range(world)]
         dist.all_gather(metas, meta, group=group)
     bufs = [torch.empty_like(points) for _ in range(world)] if rank == dst else None
+    if async_op:
+        # the collective runs on the backend's own stream / thread beside whatever the caller enqueues next; `points` must stay
+        # untouched until work.wait() (RCCL: a stream-level wait, the host does not block).  -> (work, finish) where finish()
+        # returns what the synchronous call returns
+        work = dist.gather(points, bufs, dst=dst, group=group, async_op=True)
+
+        def finish():
+            work.wait()
+            if rank != dst:
+                return None
+            ppr = pairs_per_rank if pairs_per_rank is not None else [int(m.item()) for m in metas]
+            return [bufs[r][:ppr[r]] for r in range(world)]
+        return work, finish
     dist.gather(points, bufs, dst=dst, group=group)
     if rank != dst:
         return None
