@@ -484,6 +484,48 @@ def main():
                                                       "dtype": "int8"}}
             sb2.ctx.close()
         if world == 1 and S == 1 and not args.no_extras:
+            # (c) the "next" rows of SURVEY 8f on the same frames: the tracking step as one batched call (MO_MODE_TRACK: ratio test,
+            #     displacement filter at 2 % of (w + h) / 2, 2 x median distance filter, 8-point E RANSAC at 1 px - tracker.py:214-254)
+            #     and one keyframe pair through the fundamental-matrix RANSAC of local_mapper.py:116-149 (host API)
+            sbt = subs[0]  # the headline context (a fresh context allocated after other contexts were freed ran 40 % slower: its
+            #                buffers land in recycled, fragmented device memory and every latency-bound kernel pays for it)
+            sel = torch.zeros((n_pairs, CAP, 2), dtype=torch.int32, device=dev)
+            seln = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
+            sbt.io.mode = V.MODE_TRACK; sbt.io.disp_frac = 0.02; sbt.io.thr_px = 1.0
+            sbt.io.d_sel_idx = sel.data_ptr(); sbt.io.d_sel_n = seln.data_ptr()
+            t_pw = time.perf_counter()  # (clock ramp after the PCIe-bound legs above, as ahead of the headline region)
+            while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+                sbt.launch()
+                torch.cuda.synchronize()
+            for _ in range(max(1, args.warmup)):
+                sbt.launch()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sbt.launch()
+            torch.cuda.synchronize()
+            elt = time.perf_counter() - t1
+            acct, nt_ = {}, min(args.steps, V.TIMING_SLOTS)
+            for back in range(nt_):
+                for name, ms in sbt.ctx.stage_times(back):
+                    acct[name] = acct.get(name, 0.0) + ms / nt_
+            kp0 = sbt.kps[0, :int(sbt.counts[0].item())].cpu().numpy()
+            kp1 = sbt.kps[1, :int(sbt.counts[1].item())].cpu().numpy()
+            keep = sbt.mpass[0, :len(kp0)].cpu().numpy().astype(bool)
+            tr = sbt.midx[0, :len(kp0), 0].cpu().numpy()
+            p1 = kp0[keep][:, :2].copy(); p2 = kp1[tr[keep]][:, :2].copy()
+            ctxf = V.default_context()
+            ctxf.find_fundamental(p1, p2, 3.0)
+            tsf = []
+            for _ in range(10):
+                t = time.perf_counter(); ctxf.find_fundamental(p1, p2, 3.0); tsf.append((time.perf_counter() - t) * 1e3)
+            out["next_rows"] = {"track_mode": {"value": round(B * args.steps / elt, 2), "unit": "frames/s", "ms_per_step": round(elt / args.steps * 1e3, 3),
+                                               "kept_matches_per_pair_mean": float(seln.float().mean().item()),
+                                               "stage_ms": {k: round(v, 4) for k, v in acct.items()}},
+                                "find_fundamental_ms": {"value": round(sorted(tsf)[len(tsf) // 2], 3), "correspondences": int(len(p1)),
+                                                        "note": "one pair, host API (H2D + 4096-hypothesis F RANSAC + D2H + sync)"}}
+            sbt.io.mode = V.MODE_INIT; sbt.io.thr_px = 3.0; sbt.io.d_sel_idx = None; sbt.io.d_sel_n = None
+        if world == 1 and S == 1 and not args.no_extras:
             # (a) PCIe-inclusive rate: every step first copies its frames from pinned host memory into HBM on the same stream
             #     (307 200 B per frame over Gen5 x16); never the headline value
             host = torch.empty((nb, H, W), dtype=torch.uint8).pin_memory()
