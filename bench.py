@@ -528,14 +528,16 @@ def main():
         if world == 1 and S == 1 and not args.no_extras:
             # (a) PCIe-inclusive rate: every step first copies its frames from pinned host memory into HBM on the same stream
             #     (307 200 B per frame over Gen5 x16); never the headline value
+            #     Both legs run on the HEADLINE context with its input pointer switched (a context created here, after the stand-alone
+            #     context above was destroyed, lands in recycled device memory and runs up to 40 % slower - DESIGN.md 7).
             host = torch.empty((nb, H, W), dtype=torch.uint8).pin_memory()
             host.copy_(frames.cpu())
-            dev_buf = torch.empty_like(frames)
-            sb3 = SubBatch(0, n_pairs, src=dev_buf)
+            bufs = [torch.empty_like(frames), torch.empty_like(frames)]
+            sbh = subs[0]
             def h2d_step():
-                with torch.cuda.stream(sb3.stream):
-                    dev_buf.copy_(host, non_blocking=True)
-                sb3.launch()
+                bufs[0].copy_(host, non_blocking=True)  # (current stream = the context's stream)
+                sbh.launch()
+            sbh.io.d_gray = bufs[0].data_ptr()
             for _ in range(max(1, args.warmup)):
                 h2d_step()
             torch.cuda.synchronize()
@@ -546,8 +548,6 @@ def main():
             el3 = time.perf_counter() - t1
             # (a') the same with the copy of batch i + 1 overlapped with the compute of batch i: two device buffers, a copy stream,
             #      events both ways (compute waits for its buffer's copy, the copy waits until the buffer's last reader is done)
-            bufs = [dev_buf, torch.empty_like(frames)]
-            sbs2 = [sb3, SubBatch(0, n_pairs, src=bufs[1])]  # (both on ONE compute stream: measured 4.66 ms, no overlap at all - the copy only enters at kernel tails)
             copy_s = torch.cuda.Stream(device=dev)
             copied = [torch.cuda.Event(), torch.cuda.Event()]
             freed = [torch.cuda.Event(), torch.cuda.Event()]
@@ -557,7 +557,7 @@ def main():
                     bufs[k].copy_(host, non_blocking=True)
                     copied[k].record(copy_s)
             for k in (0, 1):
-                freed[k].record(sbs2[k].stream)
+                freed[k].record(main)
             torch.cuda.synchronize()
             n_ov = args.steps + 2
             t1 = time.perf_counter()
@@ -566,18 +566,18 @@ def main():
                 k = i & 1
                 if i + 1 < n_ov:
                     enqueue_copy(1 - k)
-                sbs2[k].stream.wait_event(copied[k])
-                sbs2[k].launch()
-                freed[k].record(sbs2[k].stream)
+                main.wait_event(copied[k])
+                sbh.io.d_gray = bufs[k].data_ptr()
+                sbh.launch()
+                freed[k].record(main)
             torch.cuda.synchronize()
             el4 = time.perf_counter() - t1
+            sbh.io.d_gray = frames.data_ptr()
             out["h2d_inclusive"] = {"value": round(B * args.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 3),
                                     "overlapped_value": round(B * n_ov / el4, 2), "overlapped_ms_per_step": round(el4 / n_ov * 1e3, 3),
                                     "note": "pinned host -> HBM copy of the batch (%.1f MB) inside every step; 'overlapped': double-buffered, "
-                                            "the copy of the next batch runs on its own stream beside the compute of the current one "
-                                            "(two contexts alternate)" % (nb * H * W / 1e6)}
-            sbs2[1].ctx.close()
-            sb3.ctx.close()
+                                            "the copy of the next batch runs on its own stream beside the compute of the current one"
+                                            % (nb * H * W / 1e6)}
             # (b) single-frame latency through the drop-in classes, host arrays in and Python objects out: what the reference's
             #     Tracker would see per call (BASELINE config 2; extract_features(distributed=True) is Tracker's default path)
             from orbslam2.extractor import ORBExtractor
