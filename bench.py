@@ -389,7 +389,6 @@ def main():
                         acc[name] = acc.get(name, 0.0) + ms / 10
             alone = dict(acc)
             alone["fast_nms"] = acc["fast_nms"] - acc["blur"]
-            sbs.ctx.close()
         # roofline of the kernel on the critical path with the largest stand-alone time among the image kernels: k_fast
         crit = "fast_nms"
         crit_ms = alone[crit] if alone else per_stage[crit]
@@ -482,13 +481,11 @@ def main():
                                          "roofline": {"bound": "mfma", "kernel": "k_match_mfma", "achieved": round(tops, 1),
                                                       "peak": 5000.0, "unit": "TOP/s", "frac": round(tops / 5000.0, 4),
                                                       "dtype": "int8"}}
-            sb2.ctx.close()
         if world == 1 and S == 1 and not args.no_extras:
             # (c) the "next" rows of SURVEY 8f on the same frames: the tracking step as one batched call (MO_MODE_TRACK: ratio test,
             #     displacement filter at 2 % of (w + h) / 2, 2 x median distance filter, 8-point E RANSAC at 1 px - tracker.py:214-254)
             #     and one keyframe pair through the fundamental-matrix RANSAC of local_mapper.py:116-149 (host API)
-            sbt = subs[0]  # the headline context (a fresh context allocated after other contexts were freed ran 40 % slower: its
-            #                buffers land in recycled, fragmented device memory and every latency-bound kernel pays for it)
+            sbt = subs[0]  # the headline context with its mode switched (a SECOND context on this stream ran 40 % slower here: DESIGN.md 7)
             sel = torch.zeros((n_pairs, CAP, 2), dtype=torch.int32, device=dev)
             seln = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
             sbt.io.mode = V.MODE_TRACK; sbt.io.disp_frac = 0.02; sbt.io.thr_px = 1.0
@@ -528,8 +525,8 @@ def main():
         if world == 1 and S == 1 and not args.no_extras:
             # (a) PCIe-inclusive rate: every step first copies its frames from pinned host memory into HBM on the same stream
             #     (307 200 B per frame over Gen5 x16); never the headline value
-            #     Both legs run on the HEADLINE context with its input pointer switched (a context created here, after the stand-alone
-            #     context above was destroyed, lands in recycled device memory and runs up to 40 % slower - DESIGN.md 7).
+            #     Both legs run on the HEADLINE context with its input pointer switched (a second context on this stream ran up to 40 %
+            #     slower here - DESIGN.md 7).
             host = torch.empty((nb, H, W), dtype=torch.uint8).pin_memory()
             host.copy_(frames.cpu())
             bufs = [torch.empty_like(frames), torch.empty_like(frames)]
