@@ -449,6 +449,7 @@ def main():
             "roofline_per_stage": per_kernel,
             "stage_ms_standalone": {k: round(v, 4) for k, v in alone.items()} if alone else None,
             "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
+            "aux_stream_probe": dict(zip(("state", "fork_join_ms"), subs[0].ctx.aux_probe())),  # 1 = blur beside FAST on the aux stream
         }
         # Opt-in variant, timed outside the headline region on the same inputs: the matrix-core matcher
         # (VSLAM_AMD_MATCHER=mfma at context creation; identical results).  Its int8 operations (2 * 256 per descriptor
@@ -476,7 +477,7 @@ def main():
             c64 = sb2.counts.cpu().numpy().astype(np.float64)
             ops = float((c64[:-1] * c64[1:]).sum()) * 512.0
             tops = ops / (m_ms * 1e-3) / 1e12 if m_ms > 0 else 0.0
-            out["matcher_mfma_optin"] = {"value": round(B * args.steps / el2, 2), "unit": "frames/s",
+            out["matcher_mfma_optin"] = {"value": round(B * args.steps / el2, 2), "unit": "frames/s", "aux_stream_probe": list(sb2.ctx.aux_probe()),
                                          "ms_per_step": round(el2 / args.steps * 1e3, 3), "match_ms": round(m_ms, 4),
                                          "roofline": {"bound": "mfma", "kernel": "k_match_mfma", "achieved": round(tops, 1),
                                                       "peak": 5000.0, "unit": "TOP/s", "frac": round(tops / 5000.0, 4),

@@ -41,6 +41,7 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
         HIPCHK(c, hipMemsetAsync(c->d_pyr, c->poison, (size_t)c->batch_alloc * c->plan.pyr_stride, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_blur, c->poison, (size_t)c->batch_alloc * c->plan.blur_stride, c->stream));
     }
+    if (d_desc && (rc = mo_check_aux(c))) return rc;  // (first extraction on this stream only)
     mo_stage_begin(c);
     // margins of the levels nothing in this pipeline reads (see orb_launch_blur / orb_launch_pyramid)
     const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
@@ -50,7 +51,7 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     if (d_desc) {
         hipStream_t main_s = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, main_s));
-        hipStream_t aux = c->serial_blur ? main_s : c->aux_stream;  // serial_blur: diagnostics (stand-alone stage times)
+        hipStream_t aux = (c->serial_blur || !c->aux_ok) ? main_s : c->aux_stream;  // in line: forced (diagnostics) or the probe found no concurrency
         HIPCHK(c, hipStreamWaitEvent(aux, c->ev_fork, 0));
         c->stream = aux;
         if (c->timing) hipEventRecord(c->tsets[c->tcur].aux0, aux);

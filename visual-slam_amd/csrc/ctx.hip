@@ -62,7 +62,7 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
             hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
     }
     if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
-    if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] == '1';
+    if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) { c->serial_blur = e[0] == '1'; c->aux_forced = true; c->aux_ok = !c->serial_blur; }
     if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
     if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
     if (const char* e = getenv("VSLAM_AMD_POISON")) c->poison = atoi(e) & 255;
@@ -124,6 +124,52 @@ extern "C" void mo_destroy(mo_ctx* c) {
 }
 
 extern "C" const char* mo_last_error(mo_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+// ---- does the aux stream really run beside the context stream? ---------------------------------------------------------
+// HIP maps streams onto a handful of hardware queues by creation order.  When the aux stream shares its queue with the stream
+// it forks from and joins into, the blur's fork / join serialises behind unrelated packets: measured 2.2 -> 2.6 - 3.1 ms per
+// 256-frame step for a second context on a shared stream, while the same context with the blur in line is at full speed
+// (DESIGN.md 7).  One probe per (context, stream) pair, at the first extraction on that stream: a one-workgroup spin kernel on each
+// of the two streams, forked and joined like the blur; concurrent streams finish in the time of one, a shared queue needs two.
+// The probe synchronises the stream once (documented in vslam_amd.h); VSLAM_AMD_SERIAL_BLUR=0 / 1 forces the answer.
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+}
+
+int mo_check_aux(mo_ctx* c) {
+    if (c->aux_forced || c->aux_checked_for == (void*)c->stream) return MO_OK;
+    c->aux_checked_for = (void*)c->stream;
+    c->aux_ok = false;
+    if (!c->aux_stream) return MO_OK;
+    hipEvent_t e0, e1, e2;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
+    const long long ticks = 4000;  // 40 us at the 100 MHz constant clock
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, e0, 0));
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->aux_stream, ticks);
+        HIPCHK(c, hipEventRecord(e1, c->aux_stream));
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, ticks);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, e1, 0));
+        HIPCHK(c, hipEventRecord(e2, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e2));
+        best = std::min(best, ms);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    c->aux_probe_ms = best;
+    c->aux_ok = best < 0.080f;  // measured: 0.060 ms fork-to-join when the two 0.040 ms spins overlap, >= 0.100 ms when they queue up
+    return MO_OK;
+}
+
+extern "C" int mo_dbg_aux_probe(mo_ctx* c, float* probe_ms) {
+    if (!c) return MO_ERR_ARG;
+    if (probe_ms) *probe_ms = c->aux_probe_ms;
+    return c->aux_forced ? (c->aux_ok ? 3 : 2) : c->aux_checked_for != (void*)c->stream ? -1 : c->aux_ok ? 1 : 0;
+}
 
 extern "C" int mo_set_stream(mo_ctx* c, void* s) {
     if (!c) return MO_ERR_ARG;

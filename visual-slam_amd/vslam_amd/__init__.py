@@ -85,6 +85,7 @@ SIGNATURES = {
     "mo_gather_map_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
     "mo_stage_times_back": (_i, [_vp, _i, _vp, _vp, _i]),
+    "mo_dbg_aux_probe": (_i, [_vp, _vp]),
     "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dbg_fast_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "mo_dbg_retain_best": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -213,6 +214,12 @@ class Context:
     def gather_map_points(self, d_local_ptr, rows_local, rows_max, cap, root, d_all_ptr, d_rows_all_ptr):
         self._check(self.lib.mo_gather_map_points(self.h, C.c_void_p(d_local_ptr), int(rows_local), int(rows_max), int(cap), int(root),
                                                   C.c_void_p(d_all_ptr) if d_all_ptr else None, C.c_void_p(d_rows_all_ptr)))
+
+    def aux_probe(self):
+        """(state, probe_ms): 1 = blur on the aux stream, 0 = in line after the probe, -1 = not probed yet, 2 / 3 = forced by env"""
+        ms = C.c_float(0.0)
+        st = self.lib.mo_dbg_aux_probe(self.h, C.byref(ms))
+        return int(st), float(ms.value)
 
     def stage_times(self, back=0):
         """(name, ms) per stage of the call `back` calls ago (0 = the last; the library keeps TIMING_SLOTS event sets)"""
