@@ -248,6 +248,26 @@ def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     O.lib().orc_set_variant(1, 0)
 
 
+def test_aux_stream_probe_states(monkeypatch):
+    """mo_dbg_aux_probe: -1 before the first extraction on a stream, 0 / 1 after it (blur in line / on the aux stream), 2 when
+    VSLAM_AMD_SERIAL_BLUR=1 forces the blur in line; results are the same either way."""
+    import vslam_amd as V
+    p = V.orb_params(nfeatures=500)
+    img = synthetic_frame(11)
+    c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+    assert c.aux_probe()[0] == -1
+    (k1, d1), = c.orb_detect_compute(img, p)
+    st, ms = c.aux_probe()
+    assert st in (0, 1) and 0.02 < ms < 1.0
+    c.close()
+    monkeypatch.setenv("VSLAM_AMD_SERIAL_BLUR", "1")
+    c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+    (k2, d2), = c.orb_detect_compute(img, p)
+    assert c.aux_probe()[0] == 2
+    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
+    c.close()
+
+
 def test_stage_times_ring(ctx):
     """mo_stage_times_back: one event set per call, readable after later calls (bench.py reads a whole timed region after ONE sync)."""
     import vslam_amd as V
