@@ -52,6 +52,19 @@ def match(ctx):
                                           midx.data_ptr(), mdist.data_ptr(), mpass.data_ptr()))
 
 
+def spins(streams, cyc=20_000_000):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for st in streams:
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(cyc)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) * 1e3
+
+
+# are the two streams concurrent at all in THIS process (stream -> hardware queue mapping depends on creation order)?
+torch.cuda._sleep(1000)
+print("one spinning workgroup on stream A: %.2f ms, on A and B: %.2f ms (equal = the two streams run side by side)" % (spins([sa]), spins([sa, sb])))
 extract(cb, kps, desc, cnt)  # the descriptors stream B matches
 torch.cuda.synchronize()
 
@@ -70,6 +83,7 @@ def timed(fn, n=20):
 a = timed(lambda: extract(ca, kps2, desc2, cnt2))
 b = timed(lambda: match(cb))
 both = timed(lambda: (extract(ca, kps2, desc2, cnt2), match(cb)))
+print("aux probes: context A %s, context B %s" % (ca.aux_probe(), cb.aux_probe()))
 print("extract alone %.3f ms, match alone %.3f ms, serial sum %.3f ms, both streams %.3f ms" % (a, b, a + b, both))
 # the matcher started together with the extraction only meets its vector-bound head (pyramid, FAST, blur); two and three
 # back-to-back match calls reach into the latency-bound tail (selection, describe)
