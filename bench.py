@@ -8,8 +8,10 @@ consecutive frame pair (brute-force Hamming 2-NN + ratio test), two-view pose + 
 
 Workload at N=1: BASELINE.json configs[2] "batch of 256 synthetic 640x480 frames, extract+match pipeline"
 plus the two-view stage of configs[3] on every pair.  N>1: frames are independent, so the global frame
-sequence is sharded contiguously (weak scaling: 256 frames per rank); each rank re-extracts the one frame
-preceding its shard (halo) instead of receiving it, and the only collective is the RCCL gather of map points.
+sequence is sharded contiguously (weak scaling: 512 frames per rank by default, so that 8 ranks process BASELINE
+config 5's 4096 frames); each rank re-extracts the one frame preceding its shard (halo) instead of receiving it, and
+the only collective is the RCCL gather of map points (issued asynchronously: it runs beside the next step's kernels and
+is drained inside the timed region).
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via torch.distributed.run (one rank per GPU).
 Prints ONE JSON line on rank 0.
