@@ -459,7 +459,9 @@ def main():
         if world == 1 and S == 1 and not args.no_optin:
             os.environ["VSLAM_AMD_MATCHER"] = "mfma"
             try:
-                sb2 = SubBatch(0, n_pairs)
+                # (BENCH_OPTIN_MAIN=1, diagnostic: this context on the headline stream - the layout in which its aux stream did not
+                #  run beside it)
+                sb2 = SubBatch(0, n_pairs, stream=main if os.environ.get("BENCH_OPTIN_MAIN") else None)
             finally:
                 os.environ.pop("VSLAM_AMD_MATCHER", None)
             for _ in range(max(1, args.warmup)):

@@ -234,8 +234,8 @@ int mo_stage_times_back(mo_ctx*, int back, const char*** names, float* ms, int c
 
 /* The library runs the Gaussian blur on an auxiliary stream beside FAST + selection when that stream really runs beside the context
  * stream: HIP maps streams onto a few hardware queues, and a shared queue serialises the fork / join badly.  The FIRST extraction on a
- * given context stream therefore times a two-kernel fork / join once (it synchronises the stream that one time) and falls back to the
- * blur in line when the two spin kernels did not overlap.  Returns 1 = aux stream in use, 0 = in line after the probe, -1 = not probed
+ * given context stream therefore times a two-kernel fork / join once (it synchronises the stream that one time), replaces an auxiliary
+ * stream whose spin kernel did not overlap by a fresh one (up to three times) and falls back to the blur in line when none does.  Returns 1 = aux stream in use, 0 = in line after the probe, -1 = not probed
  * yet for the current stream, 2 / 3 = forced in line / on the aux stream by VSLAM_AMD_SERIAL_BLUR=1 / 0; probe_ms = fork-to-join time of
  * the probe (0.04 ms when concurrent, 0.08 ms when serialised). */
 int mo_dbg_aux_probe(mo_ctx*, float* probe_ms);

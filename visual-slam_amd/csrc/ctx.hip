@@ -145,24 +145,43 @@ int mo_check_aux(mo_ctx* c) {
     hipEvent_t e0, e1, e2;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
     const long long ticks = 4000;  // 40 us at the 100 MHz constant clock
-    float best = 1e9f;
-    for (int rep = 0; rep < 3; rep++) {
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, e0, 0));
-        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->aux_stream, ticks);
-        HIPCHK(c, hipEventRecord(e1, c->aux_stream));
-        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, ticks);
-        HIPCHK(c, hipStreamWaitEvent(c->stream, e1, 0));
-        HIPCHK(c, hipEventRecord(e2, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e2));
-        best = std::min(best, ms);
+    auto measure = [&](float& best) -> int {
+        best = 1e9f;
+        for (int rep = 0; rep < 3; rep++) {
+            HIPCHK(c, hipEventRecord(e0, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, e0, 0));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->aux_stream, ticks);
+            HIPCHK(c, hipEventRecord(e1, c->aux_stream));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, ticks);
+            HIPCHK(c, hipStreamWaitEvent(c->stream, e1, 0));
+            HIPCHK(c, hipEventRecord(e2, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, e0, e2));
+            best = std::min(best, ms);
+        }
+        return MO_OK;
+    };
+    // measured: 0.060 ms fork-to-join when the two 0.040 ms spins overlap, >= 0.100 ms when they queue up.  A stream that does not
+    // overlap is replaced by a NEW one (the next one the runtime hands out usually sits on another queue), at most three times.
+    int rc = MO_OK;
+    for (int attempt = 0; attempt < 4 && rc == MO_OK; attempt++) {
+        float best;
+        if ((rc = measure(best))) break;
+        c->aux_probe_ms = best;
+        c->aux_ok = best < 0.080f;
+        c->aux_attempts = attempt + 1;
+        if (c->aux_ok || attempt == 3) break;
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, lo) != hipSuccess) break;
+        hipStreamSynchronize(c->aux_stream);
+        hipStreamDestroy(c->aux_stream);
+        c->aux_stream = fresh;
     }
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-    c->aux_probe_ms = best;
-    c->aux_ok = best < 0.080f;  // measured: 0.060 ms fork-to-join when the two 0.040 ms spins overlap, >= 0.100 ms when they queue up
-    return MO_OK;
+    return rc;
 }
 
 extern "C" int mo_dbg_aux_probe(mo_ctx* c, float* probe_ms) {
