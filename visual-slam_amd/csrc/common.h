@@ -79,6 +79,7 @@ struct mo_ctx {
     bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
     bool aux_forced = false, aux_ok = false;  // aux_ok: the aux stream runs beside c->stream (mo_check_aux probes it once per stream)
     void* aux_checked_for = (void*)-1; float aux_probe_ms = 0.f; int aux_attempts = 0;
+    void* aux_seen[8] = {}; bool aux_seen_ok[8] = {}; int n_aux_seen = 0;  // probe results per context stream
     hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;

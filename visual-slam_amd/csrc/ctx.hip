@@ -139,6 +139,8 @@ __global__ void k_spin(long long ticks) {
 
 int mo_check_aux(mo_ctx* c) {
     if (c->aux_forced || c->aux_checked_for == (void*)c->stream) return MO_OK;
+    for (int i = 0; i < c->n_aux_seen; i++)  // a caller that alternates between a few streams is probed once per stream
+        if (c->aux_seen[i] == (void*)c->stream) { c->aux_checked_for = (void*)c->stream; c->aux_ok = c->aux_seen_ok[i]; return MO_OK; }
     c->aux_checked_for = (void*)c->stream;
     c->aux_ok = false;
     if (!c->aux_stream) return MO_OK;
@@ -179,7 +181,9 @@ int mo_check_aux(mo_ctx* c) {
         hipStreamSynchronize(c->aux_stream);
         hipStreamDestroy(c->aux_stream);
         c->aux_stream = fresh;
+        c->n_aux_seen = 0;  // what was learnt about other streams held for the old aux stream
     }
+    if (rc == MO_OK && c->n_aux_seen < 8) { c->aux_seen[c->n_aux_seen] = (void*)c->stream; c->aux_seen_ok[c->n_aux_seen++] = c->aux_ok; }
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
     return rc;
 }
