@@ -86,6 +86,13 @@ int mo_orb_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int w, int
  * mo_orb_compute with angle -1 (extractor.py:135,140). */
 int mo_orb_grid_good_features(mo_ctx*, const uint8_t* img, int w, int h, int stride, int ch, int n_features, float* xy,
                               int* n_out);
+/* ORBExtractor.distribute_keypoints in ONE call (reference extractor.py:85-144, the path Tracker takes by default, tracker.py:87): the
+ * grid corners as above, KeyPoint(x, y, 31) for each of them, orb.compute on that list.  xy [64 * (n_features / 64)][2] and n_xy as in
+ * mo_orb_grid_good_features; kept_idx [n_kept] = indices into xy of the corners cv2's compute keeps (rounded position at least
+ * edge_threshold inside the image), desc [n_kept][32] their descriptors (angle -1, octave 0).  One image upload and one
+ * synchronisation instead of two each for the pair mo_orb_grid_good_features + mo_orb_compute; identical results. */
+int mo_orb_grid_detect_compute(mo_ctx*, const mo_orb_params*, const uint8_t* img, int w, int h, int stride, int ch, int n_features,
+                               float* xy, int* n_xy, int32_t* kept_idx, uint8_t* desc, int* n_kept);
 
 /* Replaces cv2.undistort(image, camera_matrix, distortion)   (utils.py:40-52, applied by run_video.py:145-149 when a distortion
  * coefficient is non-zero): initUndistortRectifyMap (new camera matrix = K, 1/32-pixel fixed-point map) + remap(INTER_LINEAR,

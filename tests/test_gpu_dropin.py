@@ -202,6 +202,26 @@ def test_distribute_keypoints_like_tracker():
     assert len(kc) == len(O.grid_good_features(a, 640))
 
 
+def test_fused_grid_detect_compute_equals_the_two_calls():
+    """mo_orb_grid_detect_compute (what ORBExtractor.distribute_keypoints calls) == mo_orb_grid_good_features followed by mo_orb_compute on
+    KeyPoint(x, y, 31) records: all corners, the indices cv2's compute keeps, their descriptors - on a textured frame, on frames whose
+    corners reach the 31-px border, and for a BGR input."""
+    import vslam_amd as V
+    from tests.helpers import synthetic_frame
+    ctx = V.Context(device=0, max_w=1024, max_h=1024, max_batch=1)
+    prm = V.orb_params(nfeatures=2000)
+    for img, nf in ((synthetic_frame(3), 2000), (synthetic_frame(4, 478, 850), 1280), (np.stack([synthetic_frame(5)] * 3, axis=2), 640)):
+        xy, kept, desc = ctx.grid_detect_compute(img, prm, nf)
+        xy2 = ctx.grid_good_features(img, nf)
+        assert np.array_equal(xy, xy2) and len(xy) > 200
+        rec = np.zeros(len(xy2), V.KP_DTYPE)
+        rec["x"] = xy2[:, 0]; rec["y"] = xy2[:, 1]; rec["size"] = 31; rec["angle"] = -1; rec["class_id"] = -1
+        kept2, desc2 = ctx.orb_compute(img, prm, rec)
+        assert np.array_equal(kept, kept2) and np.array_equal(desc, desc2)
+        assert 0 < len(kept) < len(xy)  # some corners lie within 31 px of the border and are dropped by compute
+    ctx.close()
+
+
 def test_tracker_call_sequence():
     """The call sequence of the reference's Tracker.process_frame (tracker.py:73-146, 148-196, 198-266) driven by a small
     harness with the drop-in classes: frame 0 -> set_first_frame, frame 1 -> initialize, frame 2 -> match + filters."""

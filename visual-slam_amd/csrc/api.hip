@@ -311,6 +311,65 @@ extern "C" int mo_orb_grid_good_features(mo_ctx* c, const uint8_t* img, int w, i
     return gftt_run(c, img, w, h, stride, ch, n_features, xy, n_out, nullptr);
 }
 
+// ORBExtractor.distribute_keypoints in one call (reference extractor.py:85-144: the grid corners, KeyPoint(x, y, 31) each, then
+// orb.compute on all of them): ONE upload of the image, the corner lists stay on the device, the records of the corners cv2 keeps are
+// built there (k_gftt_records), blur of level 0 + descriptors, ONE synchronisation.  Same outputs as mo_orb_grid_good_features followed
+// by mo_orb_compute on KeyPoint(x, y, 31) records.
+extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
+                                          int n_features, float* xy, int* n_xy, int32_t* kept_idx, uint8_t* desc, int* n_kept) {
+    if (!c) return MO_ERR_ARG;
+    if (!p || !img || !xy || !n_xy || !kept_idx || !desc || !n_kept) return mo_fail(c, MO_ERR_ARG, "NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    *n_xy = 0; *n_kept = 0;
+    if (w < 64 || h < 64 || w > c->max_w || h > c->max_h) return mo_fail(c, MO_ERR_ARG, "image size outside the context limits");
+    if (n_features < 64) return mo_fail(c, MO_ERR_ARG, "n_features must be >= 64 (8x8 grid)");
+    int rc = mo_build_plan(c, p, w, h, 1);
+    if (rc) return rc;
+    const uint8_t* d_gray = nullptr;
+    if ((rc = stage_images(c, img, w, h, stride, ch, 1, &d_gray))) return rc;
+    const int per_cell = n_features / 64, slots = 64 * per_cell;
+    const size_t eig_b = (size_t)w * h * sizeof(float), xy_b = (size_t)slots * 2 * sizeof(float);
+    const size_t o_xy = eig_b, o_n = o_xy + xy_b, o_c2 = o_n + 64 * sizeof(int), o_rec = (o_c2 + 2 * sizeof(int) + 15) & ~(size_t)15;
+    const size_t o_kept = o_rec + (size_t)slots * sizeof(mo_keypoint), o_desc = o_kept + (size_t)slots * sizeof(int32_t);
+    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, o_desc + (size_t)slots * 32))) return rc;
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    float* d_eig = (float*)b; float* d_xy = (float*)(b + o_xy); int* d_n = (int*)(b + o_n); int* d_c2 = (int*)(b + o_c2);
+    mo_keypoint* d_rec = (mo_keypoint*)(b + o_rec); int32_t* d_kept = (int32_t*)(b + o_kept); uint8_t* d_desc = b + o_desc;
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    mo_stage_begin(c);
+    if ((rc = gftt_launch(c, d_gray, w, h, n_features, d_eig, d_xy, d_n))) return rc;
+    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, d_rec, d_kept, d_c2))) return rc;
+    mo_stage_mark(c, "grid_good_features");
+    if ((rc = orb_launch_blur(c, d_gray, 1, 1, 0))) return rc;  // the records all sit on octave 0
+    if ((rc = orb_launch_describe_given(c, d_gray, d_rec, slots, d_desc, d_c2 + 1))) return rc;
+    mo_stage_mark(c, "compute");
+    // everything back through the pinned staging buffer behind one synchronisation
+    const size_t h_xy = 16, h_n = h_xy + xy_b, h_kept = h_n + 66 * sizeof(int), h_desc = h_kept + (size_t)slots * sizeof(int32_t);
+    if ((rc = host_stage(c, h_desc + (size_t)slots * 32))) return rc;
+    uint8_t* hs = c->h_stage;
+    HIPCHK(c, hipMemcpyAsync(hs, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + h_xy, d_xy, xy_b, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + h_n, d_n, 66 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // 64 cell counts + the two totals
+    HIPCHK(c, hipMemcpyAsync(hs + h_kept, d_kept, (size_t)slots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + h_desc, d_desc, (size_t)slots * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (((const int*)hs)[0] & 4) return mo_fail(c, MO_ERR_CAPACITY, "more than 4096 local maxima in one grid cell");
+    const int* hn = (const int*)(hs + h_n);
+    const float* hxy = (const float*)(hs + h_xy);
+    int n = 0;
+    for (int cell = 0; cell < 64; cell++)
+        for (int i = 0; i < std::min(hn[cell], per_cell); i++, n++) {
+            xy[2 * n] = hxy[((size_t)cell * per_cell + i) * 2];
+            xy[2 * n + 1] = hxy[((size_t)cell * per_cell + i) * 2 + 1];
+        }
+    const int nk = hn[65];
+    if (hn[64] != n || nk < 0 || nk > n) return mo_fail(c, MO_ERR_HIP, "grid corner counts disagree between host and device");
+    *n_xy = n; *n_kept = nk;
+    std::memcpy(kept_idx, hs + h_kept, (size_t)nk * sizeof(int32_t));
+    std::memcpy(desc, hs + h_desc, (size_t)nk * 32);
+    return MO_OK;
+}
+
 extern "C" int mo_dbg_min_eigen(mo_ctx* c, const uint8_t* gray, int w, int h, float* eig) {
     if (!c) return MO_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));

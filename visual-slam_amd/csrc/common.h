@@ -167,7 +167,9 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
                         int* d_counts);
-int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc);
+int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n = nullptr);
+int gftt_records_launch(mo_ctx* c, const float* d_xy, const int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
+                        int32_t* d_kept, int* d_counts2);
 int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order,
                             int* d_nout);
 // match_kernels.hip

@@ -175,3 +175,62 @@ int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, 
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
+
+// Fused distribute_keypoints (mo_orb_grid_detect_compute): the 64 per-cell corner lists -> KeyPoint(x, y, 31) records of the corners
+// orb.compute keeps (Feature2D::compute drops keypoints whose ROUNDED position lies within edge_threshold of the border), in list
+// order, plus their indices in the cell-major list of all corners.  One workgroup: two block scans over <= 64 x per_cell slots.
+// counts2[0] = corners in all cells, counts2[1] = records kept.
+__global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ xy, const int* __restrict__ cell_n, int per_cell, int w,
+                                                      int h, int edge, mo_keypoint* __restrict__ rec, int32_t* __restrict__ kept,
+                                                      int* __restrict__ counts2) {
+    __shared__ int s_base[65];
+    __shared__ int s_wsum[4];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        int a = 0;
+        for (int cl = 0; cl < 64; cl++) { s_base[cl] = a; a += min(cell_n[cl], per_cell); }
+        s_base[64] = a;
+        s_run = 0;
+    }
+    __syncthreads();
+    const int total = s_base[64];
+    const bool no_border = !(edge > 0 && (h <= 2 * edge || w <= 2 * edge));  // (otherwise cv2 keeps nothing)
+    for (int b0 = 0; b0 < total; b0 += 256) {  // list positions in order, 256 per trip
+        const int g = b0 + tid;
+        bool keep = false;
+        float x = 0.f, y = 0.f;
+        if (g < total) {
+            int cl = 0;
+            for (int step = 32; step > 0; step >>= 1)  // the cell whose list holds position g
+                if (cl + step < 64 && s_base[cl + step] <= g) cl += step;
+            const int i = g - s_base[cl];
+            x = xy[((size_t)cl * per_cell + i) * 2]; y = xy[((size_t)cl * per_cell + i) * 2 + 1];
+            const int xi = (int)rintf(x), yi = (int)rintf(y);  // cvRound
+            keep = no_border && (edge <= 0 || (xi >= edge && xi < w - edge && yi >= edge && yi < h - edge));
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wsum[wv] = __popcll(m);
+        __syncthreads();
+        int base = s_run;
+        for (int k = 0; k < wv; k++) base += s_wsum[k];
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (keep) {
+            mo_keypoint kp;
+            kp.x = x; kp.y = y; kp.size = 31.f; kp.angle = -1.f; kp.response = 0.f; kp.octave = 0; kp.class_id = -1;
+            rec[pos] = kp;
+            kept[pos] = g;
+        }
+        __syncthreads();
+        if (tid == 0) s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) { counts2[0] = total; counts2[1] = s_run; }
+}
+
+int gftt_records_launch(mo_ctx* c, const float* d_xy, const int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
+                        int32_t* d_kept, int* d_counts2) {
+    hipLaunchKernelGGL(k_gftt_records, dim3(1), dim3(256), 0, c->stream, d_xy, d_cell_n, per_cell, w, h, edge, d_rec, d_kept, d_counts2);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}

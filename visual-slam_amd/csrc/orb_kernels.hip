@@ -1425,10 +1425,11 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
 // compute() with caller keypoints (frame 0 of the context buffers): angle as supplied, level = kp.octave
 __global__ __launch_bounds__(256) void k_describe_given(Plan P, const uint8_t* __restrict__ gray,
                                                         const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
-                                                        const mo_keypoint* __restrict__ kps, int n,
+                                                        const mo_keypoint* __restrict__ kps, int n, const int* __restrict__ n_dev,
                                                         uint8_t* __restrict__ desc) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n_dev) n = min(n, *n_dev);  // (the fused grid path: the count of records is only known on the device)
     if (k >= n) return;
     mo_keypoint kp = kps[k];
     const int L = kp.octave;
@@ -1440,11 +1441,11 @@ __global__ __launch_bounds__(256) void k_describe_given(Plan P, const uint8_t* _
     rbrief_wave<true>(bl, lv.bpitch, img, lv.pitch, lv.w, lv.h, cx, cy, kp.angle, desc + (size_t)k * 32, lane);
 }
 
-int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc) {
+int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n) {
     if (n <= 0) return MO_OK;
     const Plan& P = c->plan;
     hipLaunchKernelGGL(k_describe_given, dim3((n + 3) / 4), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, d_kps,
-                       n, d_desc);
+                       n, d_n, d_desc);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

@@ -76,18 +76,11 @@ class ORBExtractor:
         if n_features is None:
             n_features = self.n_features
         image = np.asarray(image)
-        ctx = vslam_amd.default_context()
-        xy = ctx.grid_good_features(image, n_features)
+        # corners, KeyPoint(x, y, 31) records of the ones orb.compute keeps, and their descriptors in ONE device call
+        # (mo_orb_grid_detect_compute: one upload, one synchronisation; the records never exist as Python objects)
+        xy, kept, descriptors = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features)
         all_keypoints = [KeyPoint(x, y, 31) for x, y in xy.tolist()]  # (tolist: Python floats at once, not a numpy scalar per field)
-        if all_keypoints:
-            # the records orb.compute would rebuild from the KeyPoint objects just made (KeyPoint(x, y, 31): angle -1, response 0,
-            # octave 0, class_id -1), written straight from the corner array: the per-keypoint Python loop was most of this call
-            rec = np.zeros(len(xy), vslam_amd.KP_DTYPE)
-            rec["x"] = xy[:, 0]; rec["y"] = xy[:, 1]; rec["size"] = 31; rec["angle"] = -1; rec["class_id"] = -1
-            kept, descriptors = ctx.orb_compute(image, self.orb.prm, rec)
-            if not len(kept):
-                descriptors = None
-        else:
+        if not len(kept):
             descriptors = None
         return all_keypoints, descriptors
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "mo_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mo_orb_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mo_orb_grid_good_features": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mo_orb_grid_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mo_dbg_min_eigen": (_i, [_vp, _vp, _i, _i, _vp]),
     "mo_undistort": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dev_undistort": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -280,6 +281,21 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.mo_orb_grid_good_features(self.h, _ptr(a), w, h, w * ch, ch, int(n_features), _ptr(xy), C.byref(n)))
         return xy[:n.value].copy()
+
+    def grid_detect_compute(self, image, prm, n_features):
+        """ORBExtractor.distribute_keypoints in one device call -> (xy (N,2) float32 of ALL corners, kept (M,) int32 indices into xy
+        of the corners orb.compute keeps, desc (M,32) uint8)"""
+        a = np.ascontiguousarray(image, dtype=np.uint8)
+        ch = 3 if a.ndim == 3 else 1
+        h, w = a.shape[0], a.shape[1]
+        slots = 64 * max(int(n_features) // 64, 1)
+        xy = np.zeros((slots, 2), np.float32)
+        kept = np.zeros(slots, np.int32)
+        desc = np.zeros((slots, 32), np.uint8)
+        n, nk = C.c_int(0), C.c_int(0)
+        self._check(self.lib.mo_orb_grid_detect_compute(self.h, C.byref(prm), _ptr(a), w, h, w * ch, ch, int(n_features), _ptr(xy),
+                                                        C.byref(n), _ptr(kept), _ptr(desc), C.byref(nk)))
+        return xy[:n.value].copy(), kept[:nk.value].copy(), desc[:nk.value].copy()
 
     def undistort(self, image, K, dist):
         """cv2.undistort(image, K, dist): (H, W) or (H, W, 3) uint8 -> same shape"""
