@@ -593,28 +593,31 @@ extern "C" int mo_track_pair(mo_ctx* c, const mo_keypoint* kps1, int n1, const u
     // device layout of a two-frame batch: [kps 2 x cap][desc 2 x cap x 32][counts 2][match idx / dist / pass][sel ...][two-view outputs]
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    // (inputs first and contiguous, outputs contiguous: ONE copy each way through the pinned staging buffer, which mirrors the layout)
     const size_t o_kps = take((size_t)2 * cap * sizeof(mo_keypoint)), o_desc = take((size_t)2 * cap * 32), o_cnt = take(2 * sizeof(int32_t)),
+                 o_qt = take(2 * sizeof(int32_t)), in_end = off,
                  o_midx = take((size_t)cap * 2 * sizeof(int32_t)), o_mdist = take((size_t)cap * 2 * sizeof(int32_t)), o_mpass = take(cap),
                  o_sel = take((size_t)cap * 2 * sizeof(int32_t)), o_seld = take((size_t)cap * sizeof(int32_t)), o_seln = take(sizeof(int32_t)),
-                 o_pose = take(12 * sizeof(double)), o_E = take(9 * sizeof(double)), o_X = take((size_t)cap * 3 * sizeof(float)),
-                 o_inl = take(cap), o_np = take(sizeof(int32_t)), o_qt = take(2 * sizeof(int32_t));
+                 o_pose = take(12 * sizeof(double)), o_E = take(9 * sizeof(double)), o_inl = take(cap), o_np = take(sizeof(int32_t)),
+                 out_end = off, o_X = take((size_t)cap * 3 * sizeof(float));
     int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off);
     if (rc) return rc;
+    if ((rc = host_stage(c, out_end))) return rc;
     uint8_t* b = (uint8_t*)c->d_tmp;
+    uint8_t* hs = c->h_stage;
     mo_keypoint* d_kps = (mo_keypoint*)(b + o_kps);
     uint8_t* d_desc = b + o_desc;
     int32_t* d_cnt = (int32_t*)(b + o_cnt);
-    const int32_t cnt[2] = {n1, n2};
-    HIPCHK(c, hipMemcpyAsync(d_kps, kps1, (size_t)n1 * sizeof(mo_keypoint), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_kps + cap, kps2, (size_t)n2 * sizeof(mo_keypoint), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_desc, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_desc + (size_t)cap * 32, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(d_cnt, cnt, sizeof(cnt), hipMemcpyHostToDevice, c->stream));
+    int32_t* d_qt = (int32_t*)(b + o_qt);  // pair 0 = frame 0 (query) vs frame 1 (train)
+    const int32_t cnt[2] = {n1, n2}, qt[2] = {0, 1};
+    std::memcpy(hs + o_kps, kps1, (size_t)n1 * sizeof(mo_keypoint));
+    std::memcpy(hs + o_kps + (size_t)cap * sizeof(mo_keypoint), kps2, (size_t)n2 * sizeof(mo_keypoint));
+    std::memcpy(hs + o_desc, desc1, (size_t)n1 * 32);
+    std::memcpy(hs + o_desc + (size_t)cap * 32, desc2, (size_t)n2 * 32);
+    std::memcpy(hs + o_cnt, cnt, sizeof(cnt));
+    std::memcpy(hs + o_qt, qt, sizeof(qt));
+    HIPCHK(c, hipMemcpyAsync(b, hs, in_end, hipMemcpyHostToDevice, c->stream));
     mo_stage_begin(c);
-    // pair 0 = frame 0 (query) vs frame 1 (train)
-    int32_t* d_qt = (int32_t*)(b + o_qt);
-    const int32_t qt[2] = {0, 1};
-    HIPCHK(c, hipMemcpyAsync(d_qt, qt, sizeof(qt), hipMemcpyHostToDevice, c->stream));
     if ((rc = match_launch_pairs(c, d_desc, d_desc, (size_t)cap * 32, (size_t)cap * 32, d_cnt, d_qt, d_qt + 1, 0, 0, 1, cap, ratio,
                                  (int32_t*)(b + o_midx), (int32_t*)(b + o_mdist), b + o_mpass)))
         return rc;
@@ -632,21 +635,18 @@ extern "C" int mo_track_pair(mo_ctx* c, const mo_keypoint* kps1, int n1, const u
     a.d_n_points = (int32_t*)(b + o_np);
     if ((rc = twoview_launch(c, a))) return rc;
     mo_stage_mark(c, "track_pair");
-    int32_t ns = 0, np = 0;
-    double pose[12], Eh[9];
-    HIPCHK(c, hipMemcpyAsync(&ns, b + o_seln, sizeof(ns), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&np, b + o_np, sizeof(np), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(pose, b + o_pose, sizeof(pose), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(Eh, b + o_E, sizeof(Eh), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs + o_sel, b + o_sel, out_end - o_sel, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t ns = *(const int32_t*)(hs + o_seln);
+    const int32_t np = *(const int32_t*)(hs + o_np);
+    const double* pose = (const double*)(hs + o_pose);
+    const double* Eh = (const double*)(hs + o_E);
     ns = std::min(std::max(ns, 0), cap);
     *n_sel = ns;
     if (ns > 0) {
-        std::vector<uint8_t> mask((size_t)cap);
-        HIPCHK(c, hipMemcpyAsync(sel_idx, b + o_sel, (size_t)ns * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (sel_dist) HIPCHK(c, hipMemcpyAsync(sel_dist, b + o_seld, (size_t)ns * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(mask.data(), b + o_inl, (size_t)cap, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(sel_idx, hs + o_sel, (size_t)ns * 2 * sizeof(int32_t));
+        if (sel_dist) std::memcpy(sel_dist, hs + o_seld, (size_t)ns * sizeof(int32_t));
+        const uint8_t* mask = hs + o_inl;
         for (int j = 0; j < ns; j++) inlier[j] = mask[(size_t)sel_idx[2 * j]];  // the pose mask is indexed by query keypoint
     }
     if (ns >= 8) {  // tracker.py:234: fewer than 8 matches -> tracking fails (R, t stay NaN)
