@@ -91,3 +91,26 @@ def test_option_b_shadowing(tmp_path):
             "print('ok')" % (os.path.join(ROOT, "visual-slam_amd"), str(tmp_path / "src"), str(ref)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_keypoints_from_array_fast_path_equals_constructor():
+    """orbslam2.types.keypoints_from_array fills the slots of the cv2.KeyPoint stand-in directly (no __init__ conversions): same
+    objects, field for field and type for type, as KeyPoint(*row); round trip through keypoints_to_array is the identity."""
+    import vslam_amd as V
+    from orbslam2.types import HAVE_CV2, KeyPoint, keypoints_from_array, keypoints_to_array
+    rng = np.random.default_rng(5)
+    arr = np.zeros(257, V.KP_DTYPE)
+    arr["x"] = rng.uniform(0, 640, 257).astype(np.float32); arr["y"] = rng.uniform(0, 480, 257).astype(np.float32)
+    arr["size"] = 31 * 1.2 ** rng.integers(0, 8, 257); arr["angle"] = rng.uniform(0, 360, 257); arr["response"] = rng.uniform(0, 1e-2, 257)
+    arr["octave"] = rng.integers(0, 8, 257); arr["class_id"] = -1
+    got = keypoints_from_array(arr)
+    assert isinstance(got, tuple) and len(got) == 257
+    for k, row in zip(got, arr.tolist()):
+        ref = KeyPoint(*row)
+        for f in ("pt", "size", "angle", "response", "octave", "class_id"):
+            a, b = getattr(k, f), getattr(ref, f)
+            assert a == b and type(a) is type(b), f
+    if not HAVE_CV2:
+        assert type(got[0].pt[0]) is float and type(got[0].octave) is int
+    assert np.array_equal(keypoints_to_array(got), arr)
+    assert keypoints_from_array(arr[:0]) == ()
