@@ -6,12 +6,15 @@ extract every frame (8-level pyramid, FAST-9, retainBest x2, Harris, IC angle, b
 consecutive frame pair (brute-force Hamming 2-NN + ratio test), two-view pose + map points per pair
 (8-point E RANSAC over 4096 hypotheses, pose recovery, DLT), then the final map-point gather to rank 0.
 
-Workload at N=1: BASELINE.json configs[2] "batch of 256 synthetic 640x480 frames, extract+match pipeline"
-plus the two-view stage of configs[3] on every pair.  N>1: frames are independent, so the global frame
-sequence is sharded contiguously (weak scaling: 512 frames per rank by default, so that 8 ranks process BASELINE
-config 5's 4096 frames); each rank re-extracts the one frame preceding its shard (halo) instead of receiving it, and
-the only collective is the RCCL gather of map points (issued asynchronously: it runs beside the next step's kernels and
-is drained inside the timed region).
+Workload: BASELINE.json configs[2] "batch of 256 synthetic 640x480 frames, extract+match pipeline" plus the two-view stage of
+configs[3] on every pair, on the scene SURVEY.md 8d specifies (--scene survey8d, vslam_amd/synth.py: 8-px 0..255 texture, 400
+rectangles, N(0,3) noise, sub-pixel pan on two depth layers, <= 3 deg roll between the frames of a pair); rounds 1 - 2's easier
+scene is timed as a side leg (`scene_smooth`).  N > 1: frames are independent, so the global frame sequence is sharded
+contiguously, the SAME 256 frames per rank at every N (weak scaling; the N = 1 point is the single-GPU headline); each rank re-extracts
+the one frame preceding its shard (halo) instead of receiving it, and the only collective is the gather of map points to rank 0 -
+under --backend nccl through the library's own RCCL entry point (mo_comm_init / mo_gather_map_points) on a side stream beside
+the next step's kernels, drained inside the timed region.  At N > 1 a second timed region with 512 frames per rank is reported
+beside the headline (`config5_512_per_gpu`: 8 ranks = BASELINE config 5's 4096 frames).
 
 Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 via torch.distributed.run (one rank per GPU).
 Prints ONE JSON line on rank 0.
@@ -32,6 +35,7 @@ sys.path.insert(0, os.path.join(ROOT, "visual-slam_amd"))
 W, H, NFEAT, CAP = 640, 480, 2000, 2048
 N_HYP = 4096
 PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
+PMC_FILE = "profiles/r03_pmc_per_kernel.json"  # rocprofv3 --pmc passes of profiles/collect_r03.sh on this build and scene
 
 # algorithmic bytes per frame of each extraction stage (stage-materialised model)
 STAGE_BYTES = {
@@ -43,47 +47,15 @@ STAGE_BYTES = {
     "match_knn2_ratio": 162000,      # per PAIR: 2 x 64000 B descriptors in + 34000 B out
     "two_view": 32000,               # per PAIR: correspondences in (<= 2000 x 16 B)
 }
+STAGE_KERNELS = {"pyramid": ["k_resize2", "k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
+                 "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_match_lds"],
+                 "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_tasks", "k_tv_score", "k_tv_finish"]}
 
 
-def _scene(seed, w, h, rects_per_vga):
-    """Seeded canvas: smooth low-contrast shading + many small uniform-grey rectangles (strong, repeatable corners)
-    + N(0,1) texture noise baked in."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    cw, ch = w // 32 + 2, h // 32 + 2
-    cells = rng.uniform(90, 170, size=(ch, cw))
-    ys = (np.arange(h) + 0.5) / 32.0
-    xs = (np.arange(w) + 0.5) / 32.0
-    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
-    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
-    img = (cells[y0][:, x0] * (1 - fy) * (1 - fx) + cells[y0][:, x0 + 1] * (1 - fy) * fx +
-           cells[y0 + 1][:, x0] * fy * (1 - fx) + cells[y0 + 1][:, x0 + 1] * fy * fx)
-    for _ in range(rects_per_vga * w // W):
-        rw, rh = rng.integers(5, 22, size=2)
-        x = rng.integers(0, w - 1); y = rng.integers(0, h - 1)
-        img[y:y + rh, x:x + rw] = rng.uniform(0, 255)
-    img = img + rng.normal(0, 1.0, size=img.shape)
-    return np.clip(img, 0, 255).astype(np.float32)
-
-
-def make_frames(torch, device, first, count, seed=20250523):
-    """Frames [first, first+count) of the global synthetic sequence: a camera translating along x past a two-depth
-    scene (background pans 8 px / frame, foreground patches 16 px / frame, i.e. depths 40 and 20 baselines at
-    f = 320) plus per-frame N(0,1) sensor noise.  Non-planar, ~850 ratio-test matches per consecutive pair."""
-    span = 2048
-    wide = span + 2 * W
-    bg = torch.from_numpy(_scene(seed, wide, H, 800)).to(device)
-    fg = torch.from_numpy(_scene(seed + 1, wide, H, 800)).to(device)
-    mk = torch.from_numpy(_scene(seed + 2, wide, H, 40)).to(device)
-    out = torch.empty((count, H, W), dtype=torch.uint8, device=device)
-    for i in range(count):
-        g = first + i
-        xb, xf = (8 * g) % span, (16 * g) % span
-        gen = torch.Generator(device=device)
-        gen.manual_seed(seed * 1000003 + g)
-        fr = torch.where(mk[:, xf:xf + W] > 130.0, fg[:, xf:xf + W], bg[:, xb:xb + W])
-        fr = fr + 1.0 * torch.randn((H, W), generator=gen, device=device)
-        out[i] = fr.round().clamp_(0, 255).to(torch.uint8)
-    return out
+def make_frames(torch, device, first, count, scene="survey8d", seed=20250523):
+    """frames [first, first + count) of the global synthetic sequence (vslam_amd/synth.py), uint8 [count, H, W] on `device`"""
+    from vslam_amd import synth
+    return synth.make_frames(torch, device, first, count, scene=scene, seed=seed)
 
 
 def metric_name():
@@ -149,7 +121,7 @@ def _baseline_lib():
 def cpu_baseline(frames_u8, n_frames, K):
     """cv2 itself when the box has it (kind "reference"); otherwise the repo's own CPU restatement (kind "port",
     B4): oracle/cpu_baseline.cpp = the parity oracle's extract + match plus a C++ two-view stage, -O3, one OpenMP thread per host
-    core over frames / pairs, on the SAME batch the GPU step processes; a 1-thread run on a 16-frame sample is reported beside it."""
+    core over frames / pairs, on a bounded sample of the SAME batch the GPU step processes; a 1-thread run on 8 frames beside it."""
     try:
         import cv2  # noqa: F401
     except ImportError:
@@ -173,7 +145,7 @@ def cpu_baseline(frames_u8, n_frames, K):
     # each GPU an eighth); os.cpu_count() is reported beside it
     cores = min(os.cpu_count() or 1, int(os.environ.get("VSLAM_AMD_CPU_THREADS", "16")))
     used, t, cnt = run(n_frames, cores)
-    n1 = min(16, n_frames)
+    n1 = min(8, n_frames)
     _, t1, _ = run(n1, 1)
     return {"value": n_frames / sum(t), "unit": "frames/s", "cores": used, "host_cpu_count": os.cpu_count(), "kind": "port",
             "single_core_value": n1 / sum(t1),
@@ -188,17 +160,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="frames per rank per step (default: 256 at N = 1 = BASELINE config 3; 512 at "
-                                                        "N > 1, so that 8 ranks process BASELINE config 5's 4096 frames)")
-    ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches (HIP streams) per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="frames per rank per step (default 256 at every N = BASELINE config 3; at N > 1 a "
+                                                        "second region with 512 per rank is reported too: 8 ranks = config 5's 4096 frames)")
+    ap.add_argument("--scene", default="survey8d", choices=["survey8d", "smooth"], help="synthetic scene of the headline (vslam_amd/synth.py)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0, help="untimed steps for this long ahead of the warm-up steps (clock ramp)")
-    ap.add_argument("--sync-gather", type=int, default=0, help="N > 1: 1 = blocking gather after every step instead of the overlapped one")
+    ap.add_argument("--sync-gather", type=int, default=0, help="N > 1: 1 = the gather of a step is waited for before the next step starts")
     ap.add_argument("--sync-steps", type=int, default=0, help="1: the host waits for every step before it enqueues the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra timing of the opt-in matrix-core matcher")
-    ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the batch the CPU baseline processes (all host cores)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the stand-alone kernel timing, H2D-inclusive and single-frame legs")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the batch the CPU baseline processes (bounded sample)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other scene, next rows, H2D-inclusive, single-frame)")
     args = ap.parse_args()
 
     import torch
@@ -221,205 +193,214 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     from vslam_amd.sharding import gather_map_points, shard
-    B = args.batch if args.batch > 0 else (256 if world == 1 else 512)
-    first, nb, n_pairs, _ = shard(rank, world, B)   # rank > 0 re-extracts the frame preceding its shard (halo)
-    pairs_all = [shard(r, world, B)[2] for r in range(world)]
-    frames = make_frames(torch, dev, first, nb)
     K = np.array([[320.0, 0, 320.0], [0, 320.0, 240.0], [0, 0, 1.0]])  # configs/monocular.yaml:3
-
     prm = V.orb_params(nfeatures=NFEAT, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=7,
                        select_order=V.ORDER_LIBSTDCXX)
-    pts = torch.zeros((B, CAP, 3), dtype=torch.float32, device=dev)  # rank 0 fills B-1 pairs, the others B
-    pts_alt = torch.zeros_like(pts) if world > 1 else pts            # N > 1: steps alternate between two buffers (see step())
-    npts = torch.zeros(B, dtype=torch.int32, device=dev)
+    # An explicit stream becomes this thread's current stream: everything torch enqueues from here on (copies, fills) and the
+    # library's launches share it.
+    torch.cuda.synchronize()
+    main_s = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(main_s)
+    use_rccl = world > 1 and args.backend == "nccl"  # the gather goes through the library's own RCCL entry point
 
-    class SubBatch:
-        """A contiguous run of this rank's pairs [p0, p1) = frames [p0, p1] on its own HIP stream and context.
-        Adjacent sub-batches share one frame (re-extracted, like the inter-rank halo); concurrent streams let the
-        latency-bound kernels of one sub-batch (selection replay, two-view refit) overlap the VALU-bound ones of
-        the other."""
+    class Pipeline:
+        """This rank's context, input frames and output buffers for nb frames (n_pairs = nb - 1 consecutive pairs)."""
 
-        def __init__(self, p0, p1, src=None, stream=None):
-            self.p0, self.p1, n = p0, p1, p1 - p0 + 1
-            self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        def __init__(self, frames, first_pair, rows):
+            n = frames.shape[0]
+            self.frames, self.n = frames, n
             self.ctx = V.Context(device=local, max_w=W, max_h=H, max_batch=n)
-            self.ctx.set_stream(self.stream.cuda_stream)
-            self.kps = torch.zeros((n, CAP, 7), dtype=torch.float32, device=dev)   # 28-byte mo_keypoint records
-            self.desc = torch.zeros((n, CAP, 32), dtype=torch.uint8, device=dev)
-            self.counts = torch.zeros(n, dtype=torch.int32, device=dev)
-            self.midx = torch.zeros((n - 1, CAP, 2), dtype=torch.int32, device=dev)
-            self.mdist = torch.zeros((n - 1, CAP, 2), dtype=torch.int32, device=dev)
-            self.mpass = torch.zeros((n - 1, CAP), dtype=torch.uint8, device=dev)
-            self.pose = torch.zeros((n - 1, 12), dtype=torch.float64, device=dev)
+            self.ctx.set_stream(main_s.cuda_stream)
+            z = lambda *s, dt=torch.int32: torch.zeros(s, dtype=dt, device=dev)
+            self.kps = z(n, CAP, 7, dt=torch.float32)   # 28-byte mo_keypoint records
+            self.desc = z(n, CAP, 32, dt=torch.uint8)
+            self.counts = z(n)
+            self.midx = z(n - 1, CAP, 2); self.mdist = z(n - 1, CAP, 2); self.mpass = z(n - 1, CAP, dt=torch.uint8)
+            self.pose = z(n - 1, 12, dt=torch.float64)
+            self.pts = [z(rows, CAP, 3, dt=torch.float32) for _ in range(2 if world > 1 else 1)]  # N > 1: steps alternate (see Gather)
+            self.npts = z(rows)
             io = V.BatchIO()
-            io.d_gray = (frames if src is None else src)[p0:].data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
+            io.d_gray = frames.data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
             io.ratio = 0.75; io.thr_px = 3.0; io.n_hyp = N_HYP; io.seed = 4096
-            io.pair_index_base = first + p0  # global pair index of this sub-batch's pair 0
+            io.pair_index_base = first_pair  # global pair index of this rank's pair 0
             for i in range(9):
                 io.K[i] = float(K.reshape(9)[i])
             io.d_kps = self.kps.data_ptr(); io.d_desc = self.desc.data_ptr(); io.d_counts = self.counts.data_ptr()
             io.d_match_idx = self.midx.data_ptr(); io.d_match_dist = self.mdist.data_ptr()
             io.d_match_pass = self.mpass.data_ptr(); io.d_pose = self.pose.data_ptr()
-            io.d_points = pts[p0:].data_ptr(); io.d_n_points = npts[p0:].data_ptr()
+            io.d_points = self.pts[0].data_ptr(); io.d_n_points = self.npts.data_ptr()
             self.io = io
 
         def launch(self):
             self.ctx._check(self.ctx.lib.mo_dev_frontend_batch(self.ctx.h, C.byref(prm), C.byref(self.io)))
 
-    S = max(1, min(args.streams, n_pairs))
-    cuts = [round(j * n_pairs / S) for j in range(S + 1)]
-    # An explicit stream becomes this thread's current stream: everything torch enqueues from here on (copies, the gather's
-    # stream hand-over) and the library's launches share it.  (torch's DEFAULT stream has the handle 0, which mo_set_stream takes
-    # as "use the context's own stream": the library would then run unordered beside torch's work.)
-    torch.cuda.synchronize()
-    main = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(main)
-    assert main.cuda_stream != 0
-    # one sub-batch: it runs on the current stream itself - a side stream costs two cross-stream event hand-overs per step
-    # (wait_stream both ways, ~25 us of idle GPU each), 2 % of a 2.3 ms step
-    subs = [SubBatch(cuts[j], cuts[j + 1], stream=main if S == 1 else None) for j in range(S)]
-    stage_acc = {}
+        def stage_ms(self, n_calls):
+            acc, n = {}, min(n_calls, V.TIMING_SLOTS)
+            for back in range(n):  # the most recent calls, newest first
+                for name, ms in self.ctx.stage_times(back):
+                    acc[name] = acc.get(name, 0.0) + ms / n
+            return acc
 
-    def step_local():
-        for sb in subs:
-            if sb.stream is not main:
-                sb.stream.wait_stream(main)
-            sb.launch()
-        for sb in subs:
-            if sb.stream is not main:
-                main.wait_stream(sb.stream)
+    class Gather:
+        """The final map-point gather of a step, overlapped with the next step: steps alternate between two map-point buffers and a
+        buffer re-enters the pipeline only after the gather that read it has finished (a stream-level wait).
+        nccl: mo_gather_map_points (RCCL send / recv group behind the C-ABI) enqueued on a side stream; gloo (rehearsal on one GPU):
+        torch.distributed.gather of a host copy."""
 
-    # N > 1: the gather of step i runs on RCCL's own stream beside the kernels of step i + 1 (rank 0 receives 7 x 12.6 MB per step at
-    # N = 8, ~0.3 ms of a 4.2 ms step if the next step waited for it).  Steps alternate between two map-point buffers; a buffer is
-    # handed to the pipeline again only after the gather that read it has been waited for (a stream-level wait under RCCL).
-    # --sync-gather 1: the plain blocking gather after every step.
-    pending = [None, None]
-    step_no = [0]
+        def __init__(self, pl, B, n_pairs, pairs_all):
+            self.pl, self.B, self.n_pairs, self.pairs_all = pl, B, n_pairs, pairs_all
+            self.k = 0
+            self.pending = [None, None]
+            if use_rccl:
+                self.comm_s = torch.cuda.Stream(device=dev)
+                self.done = [torch.cuda.Event(), torch.cuda.Event()]
+                self.all = torch.zeros((world, B, CAP, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+                self.rows_all = torch.zeros(world, dtype=torch.int32, device=dev)
 
-    def step():
-        k = step_no[0] & 1
-        step_no[0] += 1
-        if world == 1 or args.sync_gather:
-            step_local()
-            if world > 1:  # final map-point gather (the only collective on the path)
-                gather_map_points(pts if args.backend == "nccl" else pts.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all)
-            return
-        if pending[k] is not None:
-            pending[k][1]()          # the gather that read this buffer two steps ago
-            pending[k] = None
-        buf = pts if k == 0 else pts_alt
-        for sb in subs:
-            sb.io.d_points = buf[sb.p0:].data_ptr()
-        step_local()
-        pending[k] = gather_map_points(buf if args.backend == "nccl" else buf.cpu(), n_pairs, dst=0, pairs_per_rank=pairs_all,
-                                       async_op=True)
+        def before_step(self):
+            k = self.k
+            if self.pending[k] is not None:
+                self.finish(k)
+            self.pl.io.d_points = self.pl.pts[k].data_ptr()
 
-    def drain():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k][1]()
-                pending[k] = None
+        def finish(self, k):
+            p = self.pending[k]
+            self.pending[k] = None
+            if p == "rccl":
+                main_s.wait_event(self.done[k])
+            elif p is not None:
+                p[1]()
 
-    # Clock ramp: after the idle seconds of frame generation and context creation the first ~100 ms of work run 3 % below the
-    # steady-state rate (10 timed steps after 2 warm-up steps: 2.30 ms per step, 40 steps: 2.24 ms).  A fixed stretch of untimed
-    # steps ahead of the W warm-up steps puts the timed region on the steady-state clock whatever K and W are.
-    t_pw = time.perf_counter()
-    while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
-        step_local()  # (no collective in here: a time-based loop runs a different number of trips on every rank)
+        def after_step(self):
+            k = self.k
+            self.k ^= 1
+            buf = self.pl.pts[k]
+            if use_rccl:
+                self.comm_s.wait_stream(main_s)
+                ctx = self.pl.ctx
+                ctx.set_stream(self.comm_s.cuda_stream)
+                ctx.gather_map_points(buf.data_ptr(), self.n_pairs, self.B, CAP, 0, self.all.data_ptr() if rank == 0 else 0,
+                                      self.rows_all.data_ptr())
+                ctx.set_stream(main_s.cuda_stream)
+                self.done[k].record(self.comm_s)
+                self.pending[k] = "rccl"
+            else:
+                self.pending[k] = gather_map_points(buf.cpu(), self.n_pairs, dst=0, pairs_per_rank=self.pairs_all, async_op=True)
+            if args.sync_gather:
+                self.finish(k)
+
+        def drain(self):
+            for k in (0, 1):
+                if self.pending[k] is not None:
+                    self.finish(k)
+
+    def timed_region(B, scene):
+        """-> (pipeline, elapsed seconds (max over ranks), n_pairs): W warm-up + K timed steps of B frames per rank"""
+        first, nb, n_pairs, first_pair = shard(rank, world, B)   # rank > 0 re-extracts the frame preceding its shard (halo)
+        pairs_all = [shard(r, world, B)[2] for r in range(world)]
+        frames = make_frames(torch, dev, first, nb, scene=scene)
+        pl = Pipeline(frames, first_pair, B)
+        ga = Gather(pl, B, n_pairs, pairs_all) if world > 1 else None
+        if use_rccl:
+            ids = [V.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            pl.ctx.comm_init(ids[0], rank, world)
+
+        def step():
+            if ga:
+                ga.before_step()
+            pl.launch()
+            if ga:
+                ga.after_step()
+
+        # Clock ramp: after the idle seconds of frame generation and context creation the first ~100 ms of work run 3 % below the
+        # steady-state rate.  A fixed stretch of untimed steps ahead of the W warm-up steps puts the timed region on the steady-state
+        # clock whatever K and W are.  (No collective in here: a time-based loop runs a different number of trips on every rank.)
+        t_pw = time.perf_counter()
+        while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+            pl.launch()
+            torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
+        if ga:
+            ga.drain()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # The K timed steps are enqueued back to back with no host synchronisation in between (the library call only enqueues; the
-    # per-stage hipEvents of every step are read AFTER the closing synchronisation from the context's ring of event sets).
-    # Reading them inside the loop - as rounds 1 and 2 did - waits for the step's last event and leaves the GPU idle while
-    # the host enqueues the next step's ~30 launches: 0.06 ms of every 2.26 ms step.
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        if args.sync_steps:
-            for sb in subs:
-                sb.ctx.sync()
-    drain()  # (inside the timed region: every gather has completed before the clock stops)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    n_hist = 0
-    for sb in subs:
-        for back in range(min(args.steps, V.TIMING_SLOTS)):  # the most recent steps of the timed region, newest first
-            for name, ms in sb.ctx.stage_times(back):
-                stage_acc[name] = stage_acc.get(name, 0.0) + ms
-        n_hist = min(args.steps, V.TIMING_SLOTS)
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # The K timed steps are enqueued back to back with no host synchronisation in between (the library call only enqueues; the
+        # per-stage hipEvents of every step are read AFTER the closing synchronisation from the context's ring of event sets).
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            if args.sync_steps:
+                pl.ctx.sync()
+        if ga:
+            ga.drain()  # (inside the timed region: every gather has completed before the clock stops)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        if use_rccl and rank == 0:  # the gathered slabs are what the ranks computed: row counts and rank 0's own slab
+            assert ga.rows_all.cpu().tolist() == pairs_all, (ga.rows_all.cpu().tolist(), pairs_all)
+            k_last = ga.k ^ 1
+            a, b = ga.all[0, :n_pairs], pl.pts[k_last][:n_pairs]
+            assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(b))
+        return pl, elapsed, n_pairs
+
+    B = args.batch if args.batch > 0 else 256
+    second = None
+    if world > 1 and args.batch <= 0:   # BASELINE config 5's shape first: 512 frames per rank (4096 at N = 8)
+        pl5, el5, _ = timed_region(512, args.scene)
+        second = {"frames_per_gpu": 512, "value": round(world * 512 * args.steps / el5, 2), "unit": "frames/s",
+                  "ms_per_step": round(el5 / args.steps * 1e3, 3), "total_frames_per_step": world * 512}
+        pl5.ctx.close()
+        del pl5
+        torch.cuda.empty_cache()
+    pl, elapsed, n_pairs = timed_region(B, args.scene)   # the headline region (its per-stage figures are reported below)
 
     if rank == 0:
-        total_frames = world * B * args.steps
+        nb = pl.n
         ms_step = elapsed / args.steps * 1e3
-        value = total_frames / elapsed
-        cnt = torch.cat([sb.counts for sb in subs]).cpu().numpy()
-        npt = npts[:n_pairs].cpu().numpy()
-        mpass_mean = float(torch.cat([sb.mpass for sb in subs]).sum(dim=1).float().mean().item())
-        per_stage = {k: v / max(n_hist, 1) for k, v in stage_acc.items()}
-        n_ext = sum(sb.io.batch for sb in subs)  # frames extracted per step (sub-batches share one frame each)
-        units_of = lambda k: n_pairs if k in ("match_knn2_ratio", "two_view") else n_ext
+        value = world * B * args.steps / elapsed
+        cnt = pl.counts.cpu().numpy()
+        npt = pl.npts[:n_pairs].cpu().numpy()
+        mpass_mean = float(pl.mpass.sum(dim=1).float().mean().item())
+        per_stage = pl.stage_ms(args.steps)
+        units_of = lambda k: n_pairs if k in ("match_knn2_ratio", "two_view") else nb
         total_alg = sum(STAGE_BYTES.get(k, 0) * units_of(k) for k in per_stage)
-        # Stand-alone kernel times: in the timed region the blur runs on a low-priority stream BESIDE fast_nms + select_harris,
-        # so those three spans are stretched by one another.  A few extra steps on a second context with the blur serialised
-        # (VSLAM_AMD_SERIAL_BLUR=1; "fast_nms" then spans blur + FAST on one stream) give each kernel's own duration.
-        alone = None
-        if world == 1 and S == 1 and not args.no_extras:
-            os.environ["VSLAM_AMD_SERIAL_BLUR"] = "1"
-            try:
-                sbs = SubBatch(0, n_pairs)
-            finally:
-                os.environ.pop("VSLAM_AMD_SERIAL_BLUR", None)
-            acc = {}
-            for it in range(3 + 10):
-                sbs.launch()
-                torch.cuda.synchronize()
-                if it >= 3:
-                    for name, ms in sbs.ctx.stage_times():
-                        acc[name] = acc.get(name, 0.0) + ms / 10
-            alone = dict(acc)
-            alone["fast_nms"] = acc["fast_nms"] - acc["blur"]
-        # roofline of the kernel on the critical path with the largest stand-alone time among the image kernels: k_fast
+        # roofline of the image kernel with the longest time: k_fast.  Every kernel runs in line on one stream (the blur too), so the
+        # hipEvent span of a stage in the timed region IS its kernels' own duration.
         crit = "fast_nms"
-        crit_ms = alone[crit] if alone else per_stage[crit]
-        alg_bytes = STAGE_BYTES[crit] * n_ext
+        crit_ms = per_stage[crit]
+        alg_bytes = STAGE_BYTES[crit] * nb
         achieved = alg_bytes / (crit_ms * 1e-3) / 1e9
         pmc = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_per_kernel.json")) as f:
+            with open(os.path.join(ROOT, PMC_FILE)) as f:
                 pmc = json.load(f)
         except Exception:
             pmc = {}
-        kf = pmc.get("kernels", {}).get("k_fast", {}) if pmc.get("batch_frames") == B else {}
+        pmc_ok = pmc.get("batch_frames") == B and pmc.get("scene") == args.scene
+        kf = pmc.get("kernels", {}).get("k_fast", {}) if pmc_ok else {}
         traffic = kf.get("hbm_bytes")  # FETCH_SIZE x 2 (guide: 16-byte-per-lane streams count half) + WRITE_SIZE, per launch
         valu = kf.get("valu_insts")    # SQ_INSTS_VALU per launch (wave instructions)
         valu_frac = valu * 2.0 / (crit_ms * 1e-3 * 2.4e9 * 1024) if valu else None  # 2 cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz
-        # the same accounting for every stage (stand-alone duration; counters summed over the stage's kernels and launches per step)
-        STAGE_KERNELS = {"pyramid": ["k_resize2", "k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
-                         "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_pair_frames", "k_match_lds"],
-                         "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_tasks", "k_tv_score", "k_tv_finish"]}
         per_kernel = None
-        if alone and pmc.get("batch_frames") == B:
-            # steps per profiled pass = launches of a once-per-step kernel (prewarm + warm-up + timed steps of profiles/collect_r02.sh)
+        if pmc_ok:
+            # steps per profiled pass = launches of a once-per-step kernel (prewarm + warm-up + timed steps of profiles/collect_r03.sh)
             per_kernel, steps_prof = {}, float(pmc["kernels"].get("k_fast", {}).get("launches", 7.0))
             for st, names in STAGE_KERNELS.items():
                 ks = [pmc["kernels"][n] for n in names if n in pmc.get("kernels", {})]
-                if not ks or st not in alone:
+                if not ks or st not in per_stage:
                     continue
-                per_step = lambda key: sum(k.get(key, 0.0) * k.get("launches", steps_prof) / steps_prof for k in ks)
-                ms_st, algb = alone[st], STAGE_BYTES.get(st, 0) * units_of(st)
+                per_step = lambda key: sum((k.get(key) or 0.0) * k.get("launches", steps_prof) / steps_prof for k in ks)
+                ms_st, algb = per_stage[st], STAGE_BYTES.get(st, 0) * units_of(st)
                 per_kernel[st] = {"kernels": names, "ms": round(ms_st, 4), "algorithmic_bytes": algb,
                                   "hbm_frac": round(algb / (ms_st * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
                                   "traffic": round(per_step("hbm_bytes")),
@@ -432,114 +413,116 @@ def main():
             "config": {"workload": "batch of %d synthetic 640x480 frames per GPU: ORB extract (2000 feat, 8 levels, FAST-7) "
                                    "+ BF-Hamming 2-NN ratio 0.75 on consecutive pairs + 8-pt E RANSAC (%d hyp) pose/DLT per pair"
                                    % (B, N_HYP),
-                       "frames_per_gpu": B, "streams_per_gpu": S, "n_features": NFEAT, "hypotheses": N_HYP,
+                       "scene": {"survey8d": "survey8d: SURVEY 8d texture (8-px cells 0..255, 400 rectangles / VGA, N(0,3) noise per frame), two "
+                                             "depth layers, sub-pixel pan 8.37 / 16.74 px per frame (bilinear resample), roll <= 3 deg per pair",
+                                 "smooth": "smooth: rounds 1-2 scene (32-px cells 90..170, small rectangles, N(0,1), whole-pixel pan, no roll)"}[args.scene],
+                       "frames_per_gpu": B, "n_features": NFEAT, "hypotheses": N_HYP,
                        "keypoints_per_frame_mean": float(cnt.mean()), "matches_per_pair_mean": mpass_mean,
                        "map_points_per_pair_mean": float(npt.mean()),
-                       "parallelism": "frame-sharded x%d, RCCL gather of map points" % world},
+                       "parallelism": "frame-sharded x%d, %s" % (world, "RCCL gather of map points through mo_gather_map_points" if use_rccl
+                                                                 else "gather of map points (torch.distributed %s)" % args.backend if world > 1
+                                                                 else "single GPU"),
+                       "rccl_ranks": world if use_rccl else 0},
             "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM_GBPS, 5), "hbm_frac": round(achieved / PEAK_HBM_GBPS, 5),
                          "valu_frac": round(valu_frac, 4) if valu_frac else None, "traffic": traffic,
+                         "traffic_source": (PMC_FILE + " (separate rocprofv3 --pmc passes of the same command, not this run)") if traffic else None,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": round(crit_ms, 4),
-                         "kernel_ms_source": "stand-alone (blur serialised)" if alone else "hipEvent span in the timed region",
+                         "kernel_ms_source": "hipEvent span in the timed region (every kernel in line on one stream)",
                          "pipeline_achieved": round(total_alg / (ms_step * 1e-3) / 1e9, 2),
-                         "note": "k_fast = the image kernel with the longest stand-alone time (the round-1 review's choice; "
-                                 "k_match_lds is longer but touches 0.04 GB per launch: see roofline_per_stage); algorithmic bytes (SURVEY 8d: "
-                                 "950 532 B per frame) / its own duration.  valu_frac = SQ_INSTS_VALU (profiles/r02_pmc_per_kernel.json) "
-                                 "x 2 cycles / (1024 SIMDs x 2.4 GHz x duration); tools/ubench.hip measures 2.3 cycles only for add/sub/"
-                                 "logic/shift-right/f32 add-mul and 4.5 for every other vector instruction at the occupancy these "
-                                 "kernels run at, so an integer kernel tops out near 0.5 on this scale (DESIGN.md 4)"},
+                         "note": "k_fast = the image kernel with the longest time; algorithmic bytes (SURVEY 8d: 950 532 B per frame) / its "
+                                 "own duration.  valu_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x duration); "
+                                 "tools/ubench.hip measures 2.3 cycles only for add/sub/logic/shift-right/f32 add-mul and 4.5 for every other "
+                                 "vector instruction at the occupancy these kernels run at, so an integer kernel tops out near 0.5 on this "
+                                 "scale (DESIGN.md 4)"},
             "roofline_per_stage": per_kernel,
-            "stage_ms_standalone": {k: round(v, 4) for k, v in alone.items()} if alone else None,
+            "roofline_per_stage_source": PMC_FILE if per_kernel else None,
             "stage_ms": {k: round(v, 4) for k, v in per_stage.items()},
-            "aux_stream_probe": dict(zip(("state", "fork_join_ms"), subs[0].ctx.aux_probe())),  # 1 = blur beside FAST on the aux stream
         }
+        if second:
+            out["config5_512_per_gpu"] = second
+        single = world == 1 and not args.no_extras
+
+        def timed_calls(n_warm=None):
+            """W warm-up + K timed launches of the headline pipeline in its current configuration -> (seconds, stage ms)"""
+            t_pw = time.perf_counter()
+            while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
+                pl.launch()
+                torch.cuda.synchronize()
+            for _ in range(max(1, args.warmup) if n_warm is None else n_warm):
+                pl.launch()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pl.launch()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1, pl.stage_ms(args.steps)
+
+        if single:
+            # (s) the other scene on the headline context (input pointer switched)
+            other = "smooth" if args.scene == "survey8d" else "survey8d"
+            fr2 = make_frames(torch, dev, 0, nb, scene=other)
+            pl.io.d_gray = fr2.data_ptr()
+            el_s, st_s = timed_calls()
+            out["scene_" + other] = {"value": round(B * args.steps / el_s, 2), "unit": "frames/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
+                                     "keypoints_per_frame_mean": float(pl.counts.float().mean().item()),
+                                     "matches_per_pair_mean": float(pl.mpass.sum(dim=1).float().mean().item()),
+                                     "stage_ms": {k: round(v, 4) for k, v in st_s.items()}}
+            pl.io.d_gray = pl.frames.data_ptr()
+            del fr2
         # Opt-in variant, timed outside the headline region on the same inputs: the matrix-core matcher
         # (VSLAM_AMD_MATCHER=mfma at context creation; identical results).  Its int8 operations (2 * 256 per descriptor
         # pair) are priced against the dense int8 MFMA peak (2 x the bf16 rate, MI355X_MICROARCH.md).
-        if world == 1 and S == 1 and not args.no_optin:
+        if world == 1 and not args.no_optin:
             os.environ["VSLAM_AMD_MATCHER"] = "mfma"
             try:
-                # (BENCH_OPTIN_MAIN=1, diagnostic: this context on the headline stream - the layout in which its aux stream did not
-                #  run beside it)
-                sb2 = SubBatch(0, n_pairs, stream=main if os.environ.get("BENCH_OPTIN_MAIN") else None)
+                pl2 = Pipeline(pl.frames, 0, B)
             finally:
                 os.environ.pop("VSLAM_AMD_MATCHER", None)
             for _ in range(max(1, args.warmup)):
-                sb2.launch()
+                pl2.launch()
             torch.cuda.synchronize()
-            acc2 = {}
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                sb2.launch()
+                pl2.launch()
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
-            n2 = min(args.steps, V.TIMING_SLOTS)
-            for back in range(n2):
-                for name, ms in sb2.ctx.stage_times(back):
-                    acc2[name] = acc2.get(name, 0.0) + ms
-            m_ms = acc2.get("match_knn2_ratio", 0.0) / n2
-            c64 = sb2.counts.cpu().numpy().astype(np.float64)
+            m_ms = pl2.stage_ms(args.steps).get("match_knn2_ratio", 0.0)
+            c64 = pl2.counts.cpu().numpy().astype(np.float64)
             ops = float((c64[:-1] * c64[1:]).sum()) * 512.0
             tops = ops / (m_ms * 1e-3) / 1e12 if m_ms > 0 else 0.0
-            out["matcher_mfma_optin"] = {"value": round(B * args.steps / el2, 2), "unit": "frames/s", "aux_stream_probe": list(sb2.ctx.aux_probe()),
+            out["matcher_mfma_optin"] = {"value": round(B * args.steps / el2, 2), "unit": "frames/s",
                                          "ms_per_step": round(el2 / args.steps * 1e3, 3), "match_ms": round(m_ms, 4),
                                          "roofline": {"bound": "mfma", "kernel": "k_match_mfma", "achieved": round(tops, 1),
                                                       "peak": 5000.0, "unit": "TOP/s", "frac": round(tops / 5000.0, 4),
                                                       "dtype": "int8"}}
-        if world == 1 and S == 1 and not args.no_extras:
-            # (c) the "next" rows of SURVEY 8f on the same frames: the tracking step as one batched call (MO_MODE_TRACK: ratio test,
-            #     displacement filter at 2 % of (w + h) / 2, 2 x median distance filter, 8-point E RANSAC at 1 px - tracker.py:214-254)
-            #     and one keyframe pair through the fundamental-matrix RANSAC of local_mapper.py:116-149 (host API)
-            sbt = subs[0]  # the headline context with its mode switched (a SECOND context on this stream ran 40 % slower here: DESIGN.md 7)
+            pl2.ctx.close()
+            del pl2
+        if single:
+            # (c) the "next" rows of SURVEY 8f on the same frames, each as one batched call on the headline context:
+            #     tracking step (MO_MODE_TRACK: ratio test, displacement filter at 2 % of (w + h) / 2, 2 x median distance filter,
+            #     8-point E RANSAC at 1 px - tracker.py:214-254)
             sel = torch.zeros((n_pairs, CAP, 2), dtype=torch.int32, device=dev)
             seln = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
-            sbt.io.mode = V.MODE_TRACK; sbt.io.disp_frac = 0.02; sbt.io.thr_px = 1.0
-            sbt.io.d_sel_idx = sel.data_ptr(); sbt.io.d_sel_n = seln.data_ptr()
-            t_pw = time.perf_counter()  # (clock ramp after the PCIe-bound legs above, as ahead of the headline region)
-            while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
-                sbt.launch()
-                torch.cuda.synchronize()
-            for _ in range(max(1, args.warmup)):
-                sbt.launch()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                sbt.launch()
-            torch.cuda.synchronize()
-            elt = time.perf_counter() - t1
-            acct, nt_ = {}, min(args.steps, V.TIMING_SLOTS)
-            for back in range(nt_):
-                for name, ms in sbt.ctx.stage_times(back):
-                    acct[name] = acct.get(name, 0.0) + ms / nt_
-            kp0 = sbt.kps[0, :int(sbt.counts[0].item())].cpu().numpy()
-            kp1 = sbt.kps[1, :int(sbt.counts[1].item())].cpu().numpy()
-            keep = sbt.mpass[0, :len(kp0)].cpu().numpy().astype(bool)
-            tr = sbt.midx[0, :len(kp0), 0].cpu().numpy()
-            p1 = kp0[keep][:, :2].copy(); p2 = kp1[tr[keep]][:, :2].copy()
-            ctxf = V.default_context()
-            ctxf.find_fundamental(p1, p2, 3.0)
-            tsf = []
-            for _ in range(10):
-                t = time.perf_counter(); ctxf.find_fundamental(p1, p2, 3.0); tsf.append((time.perf_counter() - t) * 1e3)
+            pl.io.mode = V.MODE_TRACK; pl.io.disp_frac = 0.02; pl.io.thr_px = 1.0
+            pl.io.d_sel_idx = sel.data_ptr(); pl.io.d_sel_n = seln.data_ptr()
+            elt, acct = timed_calls()
             out["next_rows"] = {"track_mode": {"value": round(B * args.steps / elt, 2), "unit": "frames/s", "ms_per_step": round(elt / args.steps * 1e3, 3),
                                                "kept_matches_per_pair_mean": float(seln.float().mean().item()),
-                                               "stage_ms": {k: round(v, 4) for k, v in acct.items()}},
-                                "find_fundamental_ms": {"value": round(sorted(tsf)[len(tsf) // 2], 3), "correspondences": int(len(p1)),
-                                                        "note": "one pair, host API (H2D + 4096-hypothesis F RANSAC + D2H + sync)"}}
-            sbt.io.mode = V.MODE_INIT; sbt.io.thr_px = 3.0; sbt.io.d_sel_idx = None; sbt.io.d_sel_n = None
-        if world == 1 and S == 1 and not args.no_extras:
+                                               "stage_ms": {k: round(v, 4) for k, v in acct.items()}}}
+            pl.io.mode = V.MODE_INIT; pl.io.thr_px = 3.0; pl.io.d_sel_idx = None; pl.io.d_sel_n = None
+            out["next_rows"].update(next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K))
+        if single:
             # (a) PCIe-inclusive rate: every step first copies its frames from pinned host memory into HBM on the same stream
             #     (SURVEY 8e: 307 200 B per frame over Gen5 x16); never the headline value
-            #     Both legs run on the HEADLINE context with its input pointer switched (a second context on this stream ran up to 40 %
-            #     slower here - DESIGN.md 7).
             host = torch.empty((nb, H, W), dtype=torch.uint8).pin_memory()
-            host.copy_(frames.cpu())
-            bufs = [torch.empty_like(frames), torch.empty_like(frames)]
-            sbh = subs[0]
+            host.copy_(pl.frames.cpu())
+            bufs = [torch.empty_like(pl.frames), torch.empty_like(pl.frames)]
+
             def h2d_step():
                 bufs[0].copy_(host, non_blocking=True)  # (current stream = the context's stream)
-                sbh.launch()
-            sbh.io.d_gray = bufs[0].data_ptr()
+                pl.launch()
+            pl.io.d_gray = bufs[0].data_ptr()
             for _ in range(max(1, args.warmup)):
                 h2d_step()
             torch.cuda.synchronize()
@@ -553,13 +536,14 @@ def main():
             copy_s = torch.cuda.Stream(device=dev)
             copied = [torch.cuda.Event(), torch.cuda.Event()]
             freed = [torch.cuda.Event(), torch.cuda.Event()]
+
             def enqueue_copy(k):
                 with torch.cuda.stream(copy_s):
                     copy_s.wait_event(freed[k])
                     bufs[k].copy_(host, non_blocking=True)
                     copied[k].record(copy_s)
             for k in (0, 1):
-                freed[k].record(main)
+                freed[k].record(main_s)
             torch.cuda.synchronize()
             n_ov = args.steps + 2
             t1 = time.perf_counter()
@@ -568,25 +552,27 @@ def main():
                 k = i & 1
                 if i + 1 < n_ov:
                     enqueue_copy(1 - k)
-                main.wait_event(copied[k])
-                sbh.io.d_gray = bufs[k].data_ptr()
-                sbh.launch()
-                freed[k].record(main)
+                main_s.wait_event(copied[k])
+                pl.io.d_gray = bufs[k].data_ptr()
+                pl.launch()
+                freed[k].record(main_s)
             torch.cuda.synchronize()
             el4 = time.perf_counter() - t1
-            sbh.io.d_gray = frames.data_ptr()
+            pl.io.d_gray = pl.frames.data_ptr()
             out["h2d_inclusive"] = {"value": round(B * args.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 3),
                                     "overlapped_value": round(B * n_ov / el4, 2), "overlapped_ms_per_step": round(el4 / n_ov * 1e3, 3),
                                     "note": "pinned host -> HBM copy of the batch (%.1f MB) inside every step; 'overlapped': double-buffered, "
                                             "the copy of the next batch runs on its own stream beside the compute of the current one"
                                             % (nb * H * W / 1e6)}
+            del bufs, host
             # (b) single-frame latency through the drop-in classes, host arrays in and Python objects out: what the reference's
             #     Tracker would see per call (BASELINE config 2; extract_features(distributed=True) is Tracker's default path)
             from orbslam2.extractor import ORBExtractor
             from orbslam2.matcher import DescriptorMatcher
-            f0, f1 = frames[0].cpu().numpy(), frames[1].cpu().numpy()
+            f0, f1 = pl.frames[0].cpu().numpy(), pl.frames[1].cpu().numpy()
             ex = ORBExtractor(n_features=NFEAT)
             mt = DescriptorMatcher("bruteforce-hamming", ratio_threshold=0.75)
+
             def med_ms(fn, n):
                 fn()
                 ts = []
@@ -594,8 +580,7 @@ def main():
                     t = time.perf_counter(); fn(); ts.append((time.perf_counter() - t) * 1e3)
                 return round(sorted(ts)[len(ts) // 2], 3)
             (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
-            import vslam_amd as V2
-            ctx1 = V2.default_context()
+            ctx1 = V.default_context()
             out["single_frame_ms"] = {
                 "detect_and_compute": med_ms(lambda: ex.detect_and_compute(f0), 20),
                 "detect_and_compute_native_arrays": med_ms(lambda: ctx1.orb_detect_compute(f0, ex.orb.prm), 20),
@@ -605,13 +590,32 @@ def main():
                 "note": "median wall ms per call, host numpy in / Python objects out (H2D + kernels + D2H + sync); the *_native_arrays "
                         "rows stop at numpy arrays (no KeyPoint / DMatch objects)"}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames[:args.cpu_frames].cpu().numpy(), args.cpu_frames, K)
+            nf = min(args.cpu_frames, nb)
+            out["cpu_baseline"] = cpu_baseline(pl.frames[:nf].cpu().numpy(), nf, K)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for sb in subs:
-        sb.ctx.close()
+    pl.ctx.close()
+
+
+def next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K):
+    """SURVEY 8f rows beyond the tracking step, on the headline frames: one keyframe pair through the fundamental-matrix RANSAC of
+    local_mapper.py:116-149 (host API).  (The batched grid detector and keyframe mode add their legs here as they are built.)"""
+    legs = {}
+    kp0 = pl.kps[0, :int(pl.counts[0].item())].cpu().numpy()
+    kp1 = pl.kps[1, :int(pl.counts[1].item())].cpu().numpy()
+    keep = pl.mpass[0, :len(kp0)].cpu().numpy().astype(bool)
+    tr = pl.midx[0, :len(kp0), 0].cpu().numpy()
+    p1 = kp0[keep][:, :2].copy(); p2 = kp1[tr[keep]][:, :2].copy()
+    ctxf = V.default_context()
+    ctxf.find_fundamental(p1, p2, 3.0)
+    tsf = []
+    for _ in range(10):
+        t = time.perf_counter(); ctxf.find_fundamental(p1, p2, 3.0); tsf.append((time.perf_counter() - t) * 1e3)
+    legs["find_fundamental_ms"] = {"value": round(sorted(tsf)[len(tsf) // 2], 3), "correspondences": int(len(p1)),
+                                   "note": "one pair, host API (H2D + 4096-hypothesis F RANSAC + D2H + sync)"}
+    return legs
 
 
 if __name__ == "__main__":

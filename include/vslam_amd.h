@@ -11,7 +11,8 @@
  * thread-compatible (one caller at a time), like the single-threaded reference.
  * "host" entry points take host pointers and do the H2D/D2H themselves; "mo_dev_*" entry points take
  * DEVICE pointers (inputs already resident in HBM) and enqueue on the context's stream without
- * synchronising, for the batched / multi-GPU mode and the benchmark.
+ * synchronising, for the batched / multi-GPU mode and the benchmark.  Exceptions, both one-off: the call that first sees a new
+ * (image size, ORB parameters, batch) combination builds its plan and work buffers (hipMalloc, blocking table uploads).
  */
 #ifndef VSLAM_AMD_H
 #define VSLAM_AMD_H
@@ -60,7 +61,8 @@ typedef struct {
 mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch);
 void mo_destroy(mo_ctx*);
 const char* mo_last_error(mo_ctx*); /* valid until the next call on ctx; ctx may be NULL (creation errors) */
-int mo_set_stream(mo_ctx*, void* hip_stream); /* NULL = the context's own stream */
+int mo_set_stream(mo_ctx*, void* hip_stream); /* NULL = the context's own (non-blocking) stream */
+int mo_set_stream_null(mo_ctx*);              /* the HIP null stream (handle 0, e.g. torch's default stream): mo_set_stream cannot name it */
 int mo_sync(mo_ctx*);                         /* hipStreamSynchronize on the context stream */
 int mo_device_count(void);                    /* hipGetDeviceCount, 0 when there is no GPU */
 
@@ -223,7 +225,8 @@ int mo_gather_map_points(mo_ctx*, const float* d_local, int rows_local, int rows
                          int32_t* d_rows_all);
 
 /* Status of the mo_dev_* calls enqueued since the last mo_dev_status: the kernels never fault on overflow, they clamp and
- * raise a bit.  Synchronises the context stream, copies the flag word to flags[0] (flags may be NULL; [1..3] reserved, 0)
+ * raise a bit.  Host entry points keep their own flag words (checked inside each call): interleaving them with mo_dev_* calls
+ * neither clears nor pollutes this status.  Synchronises the context stream, copies the flag word to flags[0] (flags may be NULL; [1..3] reserved, 0)
  * and clears it.  bit 0 (1): a level's internal keypoint slot overflowed (response ties at the quota cut);
  * bit 1 (2): a frame produced more keypoints than `cap` - its rows are truncated to cap while d_counts[frame] holds the
  * number it needed (so d_counts can EXCEED cap: clamp before indexing, or retry with cap >= max(d_counts));
@@ -238,14 +241,6 @@ int mo_stage_times(mo_ctx*, const char*** names, float* ms, int cap);
  * sets, one per call, so a caller can enqueue many calls back to back and read their stage times after a single synchronisation
  * instead of waiting for every call's last event (bench.py's timed region). */
 int mo_stage_times_back(mo_ctx*, int back, const char*** names, float* ms, int cap);
-
-/* The library runs the Gaussian blur on an auxiliary stream beside FAST + selection when that stream really runs beside the context
- * stream: HIP maps streams onto a few hardware queues, and a shared queue serialises the fork / join badly.  The FIRST extraction on a
- * given context stream therefore times a two-kernel fork / join once (it synchronises the stream that one time), replaces an auxiliary
- * stream whose spin kernel did not overlap by a fresh one (up to three times) and falls back to the blur in line when none does.  Returns 1 = aux stream in use, 0 = in line after the probe, -1 = not probed
- * yet for the current stream, 2 / 3 = forced in line / on the aux stream by VSLAM_AMD_SERIAL_BLUR=1 / 0; probe_ms = fork-to-join time of
- * the probe (0.04 ms when concurrent, 0.08 ms when serialised). */
-int mo_dbg_aux_probe(mo_ctx*, float* probe_ms);
 
 /* internal-stage probes used by the parity tests (device pipeline, host in/out) */
 int mo_dbg_pyramid_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level, int blurred,

@@ -248,22 +248,20 @@ def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     O.lib().orc_set_variant(1, 0)
 
 
-def test_aux_stream_probe_states(monkeypatch):
-    """mo_dbg_aux_probe: -1 before the first extraction on a stream, 0 / 1 after it (blur in line / on the aux stream), 2 when
-    VSLAM_AMD_SERIAL_BLUR=1 forces the blur in line; results are the same either way."""
+def test_aux_stream_blur_optin_same_results(monkeypatch):
+    """The blur runs in line by default; VSLAM_AMD_SERIAL_BLUR=0 forks it onto an auxiliary stream beside FAST + selection.
+    Results are the same either way, and the in-line form reports the blur as a stage of its own."""
     import vslam_amd as V
     p = V.orb_params(nfeatures=500)
     img = synthetic_frame(11)
     c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
-    assert c.aux_probe()[0] == -1
     (k1, d1), = c.orb_detect_compute(img, p)
-    st, ms = c.aux_probe()
-    assert st in (0, 1) and 0.02 < ms < 1.0
+    assert [n for n, _ in c.stage_times()] == ["pyramid", "blur", "fast_nms", "select_harris", "angle_rbrief"]
     c.close()
-    monkeypatch.setenv("VSLAM_AMD_SERIAL_BLUR", "1")
+    monkeypatch.setenv("VSLAM_AMD_SERIAL_BLUR", "0")
     c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
     (k2, d2), = c.orb_detect_compute(img, p)
-    assert c.aux_probe()[0] == 2
+    assert [n for n, _ in c.stage_times()] == ["pyramid", "fast_nms", "select_harris", "blur", "angle_rbrief"]
     assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
     c.close()
 

@@ -70,3 +70,14 @@ def test_gather_world2_equals_single_process():
     ref = fake_points(0, 2 * B - 1, 2 * B - 1).numpy()
     assert got.shape == ref.shape
     assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))
+
+
+def test_async_gather_in_a_world_of_one_has_the_same_return_shape():
+    """async_op=True returns (work, finish) whatever the world size: `work, finish = gather_map_points(..., async_op=True)` must not
+    depend on how many processes run."""
+    pts = fake_points(0, B - 1, B)
+    work, finish = gather_map_points(pts, B - 1, async_op=True)
+    assert work is None
+    got = finish()
+    ref = gather_map_points(pts, B - 1)
+    assert len(got) == len(ref) == 1 and torch.equal(torch.nan_to_num(got[0]), torch.nan_to_num(ref[0]))

@@ -8,9 +8,14 @@
 
 #include "common.h"
 
+// Flag words: kernels raise bits in c->flags_cur[0].  mo_dev_* calls point it at words 0..3 (accumulated until mo_dev_status reads
+// and clears them); host entry points point it at words 4..7, which they clear before and check after their own kernels - a host
+// call between mo_dev_frontend_batch and mo_dev_status neither erases nor inherits the pending device-call bits.
+static inline int* host_flags(mo_ctx* c) { return c->d_flags + 4; }
+
 static int check_flags(mo_ctx* c) {
     int f[4] = {0, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(f, c->d_flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(f, host_flags(c), sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (f[0] & 1) return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)");
     if (f[0] & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
@@ -35,29 +40,35 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     int rc = mo_build_plan(c, p, w, h, batch);
     if (rc) return rc;
     if (cap < 1) return mo_fail(c, MO_ERR_ARG, "cap must be >= 1");
-    // host calls check the flags themselves before they return; mo_dev_* calls accumulate them until mo_dev_status
-    if (host_call) HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    // host calls check their own flag words before they return; mo_dev_* calls accumulate theirs until mo_dev_status
+    c->flags_cur = host_call ? host_flags(c) : c->d_flags;
+    if (host_call) HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));
     if (c->poison >= 0) {  // VSLAM_AMD_POISON=<byte> (tests): whatever the margins skip must never reach a result
         HIPCHK(c, hipMemsetAsync(c->d_pyr, c->poison, (size_t)c->batch_alloc * c->plan.pyr_stride, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_blur, c->poison, (size_t)c->batch_alloc * c->plan.blur_stride, c->stream));
     }
-    if (d_desc && (rc = mo_check_aux(c))) return rc;  // (first extraction on this stream only)
     mo_stage_begin(c);
     // margins of the levels nothing in this pipeline reads (see orb_launch_blur / orb_launch_pyramid)
     const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
     if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels, pyr_margin))) return rc;
     mo_stage_mark(c, "pyramid");
-    // the Gaussian blur only depends on the pyramid: it runs on the aux stream beside FAST + selection
-    if (d_desc) {
+    // The Gaussian blur only depends on the pyramid.  Default: in line, right behind the pyramid.  VSLAM_AMD_SERIAL_BLUR=0 (opt-in)
+    // forks it onto the auxiliary stream beside FAST + selection; measured (profiles/r02_ab_serial_blur.txt) that form gains <= 1 %
+    // and only when the runtime happens to map the two streams onto different hardware queues.
+    const bool aux_blur = d_desc && !c->serial_blur && c->aux_stream;
+    if (d_desc && !aux_blur) {
+        if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin))) return rc;
+        mo_stage_mark(c, "blur");
+    }
+    if (aux_blur) {
         hipStream_t main_s = c->stream;
         HIPCHK(c, hipEventRecord(c->ev_fork, main_s));
-        hipStream_t aux = (c->serial_blur || !c->aux_ok) ? main_s : c->aux_stream;  // in line: forced (diagnostics) or the probe found no concurrency
-        HIPCHK(c, hipStreamWaitEvent(aux, c->ev_fork, 0));
-        c->stream = aux;
-        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux0, aux);
+        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        c->stream = c->aux_stream;
+        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux0, c->aux_stream);
         rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin);
-        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux1, aux);
-        hipEventRecord(c->ev_join, aux);
+        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux1, c->aux_stream);
+        hipEventRecord(c->ev_join, c->aux_stream);
         c->stream = main_s;
         if (rc) return rc;
     }
@@ -65,7 +76,7 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     mo_stage_mark(c, "fast_nms");
     if ((rc = orb_launch_select(c, d_gray, batch))) return rc;
     mo_stage_mark(c, "select_harris");
-    if (d_desc) {
+    if (aux_blur) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
         mo_stage_mark(c, "blur");  // time taken from the aux-stream events; on the main stream this is only the join
         c->tsets[c->tcur].aux_stage = c->tsets[c->tcur].n_stages - 1;
@@ -141,7 +152,7 @@ extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const ui
     if (total <= (size_t)2 << 20) {
         if ((rc = host_stage(c, total))) return rc;
         uint8_t* hs = c->h_stage;
-        HIPCHK(c, hipMemcpyAsync(hs, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hs, host_flags(c), 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hs + o_cnt, c->d_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hs + o_kps, c->d_kps, n_rows * sizeof(mo_keypoint), hipMemcpyDeviceToHost, c->stream));
         if (desc) HIPCHK(c, hipMemcpyAsync(hs + o_desc, c->d_desc, n_rows * 32, hipMemcpyDeviceToHost, c->stream));
@@ -279,7 +290,8 @@ static int gftt_run(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int
     float* d_eig = (float*)c->d_tmp;
     float* d_xy = (float*)((uint8_t*)c->d_tmp + eig_b);
     int* d_n = (int*)((uint8_t*)d_xy + xy_b);
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    c->flags_cur = host_flags(c);
+    HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));
     mo_stage_begin(c);
     if ((rc = gftt_launch(c, d_gray, w, h, n_features, d_eig, d_xy, d_n))) return rc;
     mo_stage_mark(c, "grid_good_features");
@@ -289,7 +301,7 @@ static int gftt_run(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int
     HIPCHK(c, hipMemcpyAsync(hxy.data(), d_xy, xy_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hn, d_n, sizeof(hn), hipMemcpyDeviceToHost, c->stream));
     int f[4];
-    HIPCHK(c, hipMemcpyAsync(f, c->d_flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(f, host_flags(c), sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (f[0] & 4) return mo_fail(c, MO_ERR_CAPACITY, "more than 4096 local maxima in one grid cell");
     int n = 0;
@@ -335,7 +347,8 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     uint8_t* b = (uint8_t*)c->d_tmp;
     float* d_eig = (float*)b; float* d_xy = (float*)(b + o_xy); int* d_n = (int*)(b + o_n); int* d_c2 = (int*)(b + o_c2);
     mo_keypoint* d_rec = (mo_keypoint*)(b + o_rec); int32_t* d_kept = (int32_t*)(b + o_kept); uint8_t* d_desc = b + o_desc;
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
+    c->flags_cur = host_flags(c);
+    HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));
     mo_stage_begin(c);
     if ((rc = gftt_launch(c, d_gray, w, h, n_features, d_eig, d_xy, d_n))) return rc;
     if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, d_rec, d_kept, d_c2))) return rc;
@@ -347,7 +360,7 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     const size_t h_xy = 16, h_n = h_xy + xy_b, h_kept = h_n + 66 * sizeof(int), h_desc = h_kept + (size_t)slots * sizeof(int32_t);
     if ((rc = host_stage(c, h_desc + (size_t)slots * 32))) return rc;
     uint8_t* hs = c->h_stage;
-    HIPCHK(c, hipMemcpyAsync(hs, c->d_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(hs, host_flags(c), 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + h_xy, d_xy, xy_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + h_n, d_n, 66 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // 64 cell counts + the two totals
     HIPCHK(c, hipMemcpyAsync(hs + h_kept, d_kept, (size_t)slots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -56,6 +56,8 @@ int nccl_fail(mo_ctx* c, const char* what, int rc) {
     return mo_fail(c, MO_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error"));
 }
 
+__global__ void k_store_i32(int32_t* p, int32_t v) { *p = v; }
+
 }  // namespace
 
 extern "C" int mo_comm_unique_id(uint8_t id[128]) {
@@ -109,16 +111,22 @@ extern "C" int mo_gather_map_points(mo_ctx* c, const float* d_local, int rows_lo
     // 1. per-rank row counts (one int each): all-gather, so that every rank can index the result
     int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, 256);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_tmp, &rows_local, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    // (the count travels as a kernel argument: an async copy from this function's stack would outlive the variable)
+    hipLaunchKernelGGL(k_store_i32, dim3(1), dim3(1), 0, c->stream, (int32_t*)c->d_tmp, (int32_t)rows_local);
+    HIPCHK(c, hipGetLastError());
     if ((rc = r.AllGather(c->d_tmp, d_rows_all, 1, NCCL_INT32, comm, c->stream)) != 0) return nccl_fail(c, "ncclAllGather", rc);
     // 2. padded point slabs to the root: one send per rank, `world` receives on the root, one group (point-to-point over xGMI;
     //    the payload is MBs, so this is latency-bound and a ring collective would buy nothing)
     const size_t slab = (size_t)rows_max * cap * 3;
     if ((rc = r.GroupStart()) != 0) return nccl_fail(c, "ncclGroupStart", rc);
+    // an error inside the group must still close it: an open group would swallow the communicator's next collective
+    const char* what = nullptr;
     if (c->comm_rank == root)
-        for (int p = 0; p < c->comm_world; p++)
-            if ((rc = r.Recv(d_all + (size_t)p * slab, slab, NCCL_FLOAT32, p, comm, c->stream)) != 0) return nccl_fail(c, "ncclRecv", rc);
-    if ((rc = r.Send(d_local, slab, NCCL_FLOAT32, root, comm, c->stream)) != 0) return nccl_fail(c, "ncclSend", rc);
-    if ((rc = r.GroupEnd()) != 0) return nccl_fail(c, "ncclGroupEnd", rc);
+        for (int p = 0; p < c->comm_world && rc == 0; p++)
+            if ((rc = r.Recv(d_all + (size_t)p * slab, slab, NCCL_FLOAT32, p, comm, c->stream)) != 0) what = "ncclRecv";
+    if (rc == 0 && (rc = r.Send(d_local, slab, NCCL_FLOAT32, root, comm, c->stream)) != 0) what = "ncclSend";
+    const int rc_end = r.GroupEnd();
+    if (rc != 0) return nccl_fail(c, what, rc);
+    if (rc_end != 0) return nccl_fail(c, "ncclGroupEnd", rc_end);
     return MO_OK;
 }

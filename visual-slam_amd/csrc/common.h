@@ -76,11 +76,10 @@ struct mo_ctx {
     int strip_rows = MO_STRIP_ROWS;  // rows per FAST strip (VSLAM_AMD_STRIP_ROWS: A/B timing)
     int poison = -1;             // VSLAM_AMD_POISON=<0..255>: fill the pyramid buffers with that byte before every extraction (tests)
     bool blur_full = false;      // VSLAM_AMD_BLUR=full: the pipeline blurs whole levels (A/B timing)
-    bool serial_blur = false;  // VSLAM_AMD_SERIAL_BLUR=1: run the blur on the main stream (stand-alone stage timing)
-    bool aux_forced = false, aux_ok = false;  // aux_ok: the aux stream runs beside c->stream (mo_check_aux probes it once per stream)
-    void* aux_checked_for = (void*)-1; float aux_probe_ms = 0.f; int aux_attempts = 0;
-    void* aux_seen[8] = {}; bool aux_seen_ok[8] = {}; int n_aux_seen = 0;  // probe results per context stream
-    hipStream_t aux_stream = nullptr;           // runs the blur beside FAST + selection (both only depend on the pyramid)
+    bool serial_blur = true;   // the blur runs in line on the context stream (default).  VSLAM_AMD_SERIAL_BLUR=0 opts into the
+                               // aux-stream fork / join of rounds 1 - 2 (measured gain <= 1 %, and only where the runtime maps the
+                               // two streams onto different hardware queues)
+    hipStream_t aux_stream = nullptr;           // opt-in: runs the blur beside FAST + selection (both only depend on the pyramid)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
@@ -107,7 +106,9 @@ struct mo_ctx {
     int tile_margin = 0;
     uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
     int* d_lv_tab = nullptr;       // k_describe: per-level geometry table (built with the plan)
-    int* d_flags = nullptr;        // [4] error flags raised by kernels
+    int* d_flags = nullptr;        // [8] error flags raised by kernels: words 0..3 belong to the mo_dev_* calls (they accumulate until
+                                   // mo_dev_status), words 4..7 to the host entry points (cleared and checked inside each call)
+    int* flags_cur = nullptr;      // the word block the kernels of the current call raise their bits in
     unsigned lds_attr_done = 0;    // bit per kernel whose max-dynamic-LDS attribute has been raised on this device
     // output staging for the host API
     mo_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int* d_counts = nullptr; int out_cap = 0, out_batch = 0;
@@ -133,7 +134,6 @@ struct mo_ctx {
 };
 
 int mo_fail(mo_ctx* c, int code, const std::string& msg);
-int mo_check_aux(mo_ctx* c);
 
 #define HIPCHK(c, expr)                                                                              \
     do {                                                                                             \

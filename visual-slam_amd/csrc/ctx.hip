@@ -55,14 +55,15 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         return nullptr;
     }
     c->stream = c->own_stream;
-    {   // the auxiliary stream only fills idle CUs: lowest priority, so FAST + selection on the main stream keep theirs
+    if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
+    if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] != '0';
+    if (!c->serial_blur) {  // opt-in: the auxiliary stream only fills idle CUs: lowest priority, so FAST + selection on the main stream keep theirs
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess)
-            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+        if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess &&
+            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess)
+            c->serial_blur = true;
     }
-    if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
-    if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) { c->serial_blur = e[0] == '1'; c->aux_forced = true; c->aux_ok = !c->serial_blur; }
     if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
     if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
     if (const char* e = getenv("VSLAM_AMD_POISON")) c->poison = atoi(e) & 255;
@@ -78,12 +79,13 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         hipEventCreateWithFlags(&t.aux1, evf);
         for (int i = 0; i <= MO_NSTAGES; i++) hipEventCreateWithFlags(&t.ev[i], evf);
     }
-    if (hipMalloc((void**)&c->d_flags, 4 * sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void**)&c->d_flags, 8 * sizeof(int)) != hipSuccess) {
         g_create_err = "mo_create: hipMalloc failed";
         delete c;
         return nullptr;
     }
-    hipMemset(c->d_flags, 0, 4 * sizeof(int));
+    hipMemset(c->d_flags, 0, 8 * sizeof(int));
+    c->flags_cur = c->d_flags;
     return c;
 }
 
@@ -125,78 +127,17 @@ extern "C" void mo_destroy(mo_ctx* c) {
 
 extern "C" const char* mo_last_error(mo_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
-// ---- does the aux stream really run beside the context stream? ---------------------------------------------------------
-// HIP maps streams onto a handful of hardware queues by creation order.  When the aux stream shares its queue with the stream
-// it forks from and joins into, the blur's fork / join serialises behind unrelated packets: measured 2.2 -> 2.6 - 3.1 ms per
-// 256-frame step for a second context on a shared stream, while the same context with the blur in line is at full speed
-// (DESIGN.md 7).  One probe per (context, stream) pair, at the first extraction on that stream: a one-workgroup spin kernel on each
-// of the two streams, forked and joined like the blur; concurrent streams finish in the time of one, a shared queue needs two.
-// The probe synchronises the stream once (documented in vslam_amd.h); VSLAM_AMD_SERIAL_BLUR=0 / 1 forces the answer.
-__global__ void k_spin(long long ticks) {
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < ticks) {}
-}
-
-int mo_check_aux(mo_ctx* c) {
-    if (c->aux_forced || c->aux_checked_for == (void*)c->stream) return MO_OK;
-    for (int i = 0; i < c->n_aux_seen; i++)  // a caller that alternates between a few streams is probed once per stream
-        if (c->aux_seen[i] == (void*)c->stream) { c->aux_checked_for = (void*)c->stream; c->aux_ok = c->aux_seen_ok[i]; return MO_OK; }
-    c->aux_checked_for = (void*)c->stream;
-    c->aux_ok = false;
-    if (!c->aux_stream) return MO_OK;
-    hipEvent_t e0, e1, e2;
-    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1)); HIPCHK(c, hipEventCreate(&e2));
-    const long long ticks = 4000;  // 40 us at the 100 MHz constant clock
-    auto measure = [&](float& best) -> int {
-        best = 1e9f;
-        for (int rep = 0; rep < 3; rep++) {
-            HIPCHK(c, hipEventRecord(e0, c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->aux_stream, e0, 0));
-            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->aux_stream, ticks);
-            HIPCHK(c, hipEventRecord(e1, c->aux_stream));
-            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, c->stream, ticks);
-            HIPCHK(c, hipStreamWaitEvent(c->stream, e1, 0));
-            HIPCHK(c, hipEventRecord(e2, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            float ms = 0;
-            HIPCHK(c, hipEventElapsedTime(&ms, e0, e2));
-            best = std::min(best, ms);
-        }
-        return MO_OK;
-    };
-    // measured: 0.060 ms fork-to-join when the two 0.040 ms spins overlap, >= 0.100 ms when they queue up.  A stream that does not
-    // overlap is replaced by a NEW one (the next one the runtime hands out usually sits on another queue), at most three times.
-    int rc = MO_OK;
-    for (int attempt = 0; attempt < 4 && rc == MO_OK; attempt++) {
-        float best;
-        if ((rc = measure(best))) break;
-        c->aux_probe_ms = best;
-        c->aux_ok = best < 0.080f;
-        c->aux_attempts = attempt + 1;
-        if (c->aux_ok || attempt == 3) break;
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
-        hipStream_t fresh = nullptr;
-        if (hipStreamCreateWithPriority(&fresh, hipStreamNonBlocking, lo) != hipSuccess) break;
-        hipStreamSynchronize(c->aux_stream);
-        hipStreamDestroy(c->aux_stream);
-        c->aux_stream = fresh;
-        c->n_aux_seen = 0;  // what was learnt about other streams held for the old aux stream
-    }
-    if (rc == MO_OK && c->n_aux_seen < 8) { c->aux_seen[c->n_aux_seen] = (void*)c->stream; c->aux_seen_ok[c->n_aux_seen++] = c->aux_ok; }
-    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-    return rc;
-}
-
-extern "C" int mo_dbg_aux_probe(mo_ctx* c, float* probe_ms) {
-    if (!c) return MO_ERR_ARG;
-    if (probe_ms) *probe_ms = c->aux_probe_ms;
-    return c->aux_forced ? (c->aux_ok ? 3 : 2) : c->aux_checked_for != (void*)c->stream ? -1 : c->aux_ok ? 1 : 0;
-}
-
 extern "C" int mo_set_stream(mo_ctx* c, void* s) {
     if (!c) return MO_ERR_ARG;
     c->stream = s ? (hipStream_t)s : c->own_stream;
+    return MO_OK;
+}
+
+// The HIP null stream has the handle 0, which mo_set_stream reads as "the context's own stream": a caller whose work sits on the
+// null stream (torch's default stream) selects it with this call, so that the library's launches are ordered with that work.
+extern "C" int mo_set_stream_null(mo_ctx* c) {
+    if (!c) return MO_ERR_ARG;
+    c->stream = nullptr;
     return MO_OK;
 }
 

@@ -171,7 +171,7 @@ int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, 
     if (per_cell > GF_MAXCORNERS) return mo_fail(c, MO_ERR_UNSUPPORTED, "more than 256 corners per grid cell");
     hipLaunchKernelGGL(k_min_eigen, dim3((w + ME_TW - 1) / ME_TW, (h + ME_TH - 1) / ME_TH), dim3(256), 0, c->stream, d_gray, w, h, d_eig);
     hipLaunchKernelGGL(k_gftt_cell, dim3(rows * cols), dim3(256), 0, c->stream, d_eig, w, h, cols, cw, ch, per_cell, 0.01, 10.0,
-                       d_xy, d_n, c->d_flags);
+                       d_xy, d_n, c->flags_cur);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

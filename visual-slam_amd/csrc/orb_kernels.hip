@@ -803,8 +803,9 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, i
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_BUF_BYTES (33 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): 4 workgroups per CU together
-                                   // with the 3.4 KB of Harris windows and the replay scratch (19 - 37 KB measured alike)
+#define SEL_BUF_BYTES (46 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): holds the ~9000 candidates a
+                                   // dense 640x480 level 0 produces (5.125 B each with the replay's side arrays; SURVEY 8d texture: 6600 -
+                                   // 7000); 3 workgroups per CU with the 3.4 KB of Harris windows and the replay scratch
 #define SEL_MAXSTRIPS 256
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
@@ -1045,7 +1046,7 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo,
     // 0.23 - 0.25 ms against 0.20 ms; selecting the finest level on the auxiliary stream beside FAST of the others: no gain
     // (the coarse levels alone take 0.19 ms: the kernel is bound by the sum of the replays, not by the finest level).
     hipLaunchKernelGGL(k_select, dim3(batch, level_hi - level_lo), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
-                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->d_flags, level_lo, SEL_BUF_BYTES);
+                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
@@ -1414,10 +1415,10 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
     const uint32_t inv_per = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
     if (d_desc)
         hipLaunchKernelGGL(k_describe<true>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
-                           d_kps, d_desc, cap, d_counts, c->d_flags, c->d_lv_tab, inv_per);
+                           d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_lv_tab, inv_per);
     else
         hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
-                           d_kps, d_desc, cap, d_counts, c->d_flags, c->d_lv_tab, inv_per);
+                           d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_lv_tab, inv_per);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

@@ -60,6 +60,7 @@ SIGNATURES = {
     "mo_destroy": (None, [_vp]),
     "mo_last_error": (C.c_char_p, [_vp]),
     "mo_set_stream": (_i, [_vp, _vp]),
+    "mo_set_stream_null": (_i, [_vp]),
     "mo_sync": (_i, [_vp]),
     "mo_device_count": (_i, []),
     "mo_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
@@ -86,7 +87,6 @@ SIGNATURES = {
     "mo_gather_map_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
     "mo_stage_times_back": (_i, [_vp, _i, _vp, _vp, _i]),
-    "mo_dbg_aux_probe": (_i, [_vp, _vp]),
     "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dbg_fast_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "mo_dbg_retain_best": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -185,7 +185,14 @@ class Context:
             raise NativeError(rc, self.lib.mo_last_error(self.h).decode())
 
     def set_stream(self, stream_handle):
-        self._check(self.lib.mo_set_stream(self.h, C.c_void_p(stream_handle) if stream_handle else None))
+        """None: the context's own stream; 0: the HIP null stream (torch.cuda.current_stream().cuda_stream of torch's default
+        stream) - the library's launches are then ordered with the work torch has on it; otherwise a hipStream_t handle."""
+        if stream_handle is None:
+            self._check(self.lib.mo_set_stream(self.h, None))
+        elif int(stream_handle) == 0:
+            self._check(self.lib.mo_set_stream_null(self.h))
+        else:
+            self._check(self.lib.mo_set_stream(self.h, C.c_void_p(int(stream_handle))))
 
     def sync(self):
         self._check(self.lib.mo_sync(self.h))
@@ -215,12 +222,6 @@ class Context:
     def gather_map_points(self, d_local_ptr, rows_local, rows_max, cap, root, d_all_ptr, d_rows_all_ptr):
         self._check(self.lib.mo_gather_map_points(self.h, C.c_void_p(d_local_ptr), int(rows_local), int(rows_max), int(cap), int(root),
                                                   C.c_void_p(d_all_ptr) if d_all_ptr else None, C.c_void_p(d_rows_all_ptr)))
-
-    def aux_probe(self):
-        """(state, probe_ms): 1 = blur on the aux stream, 0 = in line after the probe, -1 = not probed yet, 2 / 3 = forced by env"""
-        ms = C.c_float(0.0)
-        st = self.lib.mo_dbg_aux_probe(self.h, C.byref(ms))
-        return int(st), float(ms.value)
 
     def stage_times(self, back=0):
         """(name, ms) per stage of the call `back` calls ago (0 = the last; the library keeps TIMING_SLOTS event sets)"""

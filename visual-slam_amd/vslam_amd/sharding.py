@@ -24,10 +24,12 @@ def gather_map_points(points, n_pairs, dst=0, group=None, pairs_per_rank=None, a
     with one [n_pairs_r, cap, 3] tensor per rank in global pair order, elsewhere None.
     pairs_per_rank: the pair count of every rank when the caller knows it (contiguous sharding does: shard(r, ...)[2]);
     without it the counts are exchanged with one extra all_gather and a host read per rank.
-    async_op: see below (world > 1 only; a world of one returns the synchronous result)."""
+    async_op: -> (work, finish) whatever the world size; finish() returns what the synchronous call returns (work is None in a
+    world of one: nothing is in flight)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return [points[:n_pairs]]
+        res = [points[:n_pairs]]
+        return (None, lambda: res) if async_op else res
     rank = dist.get_rank(group)
     if pairs_per_rank is None:
         meta = torch.tensor([n_pairs], dtype=torch.int64, device=points.device)
