@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra timing of the opt-in matrix-core matcher")
     ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the batch the CPU baseline processes (bounded sample)")
+    ap.add_argument("--frames-cache", default="", help="file the generated frames of this rank are kept in (.npy; created when missing): "
+                                                       "profiles/collect.sh generates once and profiles only the pipeline")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other scene, next rows, H2D-inclusive, single-frame)")
     args = ap.parse_args()
 
@@ -298,7 +300,13 @@ def main():
         """-> (pipeline, elapsed seconds (max over ranks), n_pairs): W warm-up + K timed steps of B frames per rank"""
         first, nb, n_pairs, first_pair = shard(rank, world, B)   # rank > 0 re-extracts the frame preceding its shard (halo)
         pairs_all = [shard(r, world, B)[2] for r in range(world)]
-        frames = make_frames(torch, dev, first, nb, scene=scene)
+        cache = "%s.%s.%d.%d.npy" % (args.frames_cache, scene, first, nb) if args.frames_cache else ""
+        if cache and os.path.exists(cache):
+            frames = torch.from_numpy(np.load(cache)).to(dev)
+        else:
+            frames = make_frames(torch, dev, first, nb, scene=scene)
+            if cache:
+                np.save(cache, frames.cpu().numpy())
         pl = Pipeline(frames, first_pair, B)
         ga = Gather(pl, B, n_pairs, pairs_all) if world > 1 else None
         if use_rccl:
