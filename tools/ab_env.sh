@@ -1,12 +1,12 @@
 #!/bin/bash
-# tools/ab_env.sh VAR val_a val_b [rounds]: interleaved bench.py runs with an environment knob at two values (same box, same build);
-# prints ms_per_step of every run.  Used for run-time switches read at context creation (VSLAM_AMD_*).
-var=$1; a=$2; b=$3; rounds=${4:-3}
-for r in $(seq $rounds); do
-  for v in $a $b; do
-    env $var=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-optin --no-extras | python -c "
+# tools/ab_env.sh VAR val1 val2 ... -- interleaved bench.py runs on one box with VAR set to each value in turn (3 rounds):
+# ms_per_step and the per-stage spans of every run.  Usage on the GPU box: bash tools/ab_env.sh VSLAM_AMD_DESCRIBE tiles patch
+VAR=$1; shift
+for round in 1 2 3; do
+  for v in "$@"; do
+    env $VAR=$v python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-optin --no-extras --frames-cache /tmp/bench_frames 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$var=$v', d['ms_per_step'], {k: round(x, 3) for k, x in d['stage_ms'].items()})"
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('$VAR=$v', d['ms_per_step'], ' '.join('%s %.4f' % (k, x) for k, x in d['stage_ms'].items()))"
   done
 done

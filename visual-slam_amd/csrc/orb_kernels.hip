@@ -20,7 +20,7 @@
 #include "common.h"
 #include "select_replay.h"
 
-__constant__ int8_t c_pattern[256 * 4] = {
+__constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 
@@ -1251,6 +1251,25 @@ __device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch,
     return (uint16_t)val;  // little endian: bits 0..7 = byte 2gl, bits 8..15 = byte 2gl+1
 }
 
+// The same 16 tests per lane with the lane's pattern rows held in registers (pat[k] = x0 | y0 << 8 | x1 << 16 | y1 << 24 as int8
+// of test 16 gl + k): the tile kernel describes many keypoints per lane, so the table is fetched once per workgroup.
+__device__ __forceinline__ uint16_t rbrief_u16_reg(const uint8_t* patch, int ppitch, int cx, int cy, float a, float b, const uint32_t (&pat)[16]) {
+    const int cxm = cx - 0x4B400000, cym = cy - 0x4B400000;
+    unsigned val = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t pk = pat[k];
+        const float fx0 = (float)(int8_t)(pk & 0xFF), fy0 = (float)(int8_t)((pk >> 8) & 0xFF);
+        const float fx1 = (float)(int8_t)((pk >> 16) & 0xFF), fy1 = (float)(int8_t)(pk >> 24);
+        const int jx0 = __float_as_int((fx0 * a - fy0 * b) + 12582912.f), jy0 = __float_as_int((fx0 * b + fy0 * a) + 12582912.f);
+        const int jx1 = __float_as_int((fx1 * a - fy1 * b) + 12582912.f), jy1 = __float_as_int((fx1 * b + fy1 * a) + 12582912.f);
+        const int t0 = patch[__mul24(cym + jy0, ppitch) + cxm + jx0];
+        const int t1 = patch[__mul24(cym + jy1, ppitch) + cxm + jx1];
+        val |= (t0 < t1 ? 1u : 0u) << k;
+    }
+    return (uint16_t)val;
+}
+
 // One 16-lane group (a quarter wavefront) per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred
 // patch (rBRIEF) pass through the same group-private LDS patch one after the other: all global loads of both windows are
 // issued up front into registers, the raw window is stored and reduced to the angle while the blurred one is still in
@@ -1386,7 +1405,244 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
     }
 }
 
-int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
+// ------------------------------------------------------------------ describe, tile form (round 3) -------------------
+// The per-keypoint kernel above gathers two private windows per keypoint from global memory (31 x 36 B raw + 39 x 44 B blurred in
+// 48 dword loads per lane: ~130 cache-line requests per keypoint, 1.45 GB through the vector L1 per 256-frame launch, a wavefront
+// spent 8 - 21 k of its 30 k cycles waiting for them) and parks them in LDS through registers (93 VGPRs, 5 wavefronts per SIMD).
+// Here a workgroup owns a 128 x 64 TILE of one level's border region: it picks the level's final keypoints that fall into the tile
+// (the level's list is <= a few KB, read coalesced), loads the tile + halo of the raw level (15 px: intensity centroid) and of the
+// blurred level (19 px: rBRIEF) ONCE with coalesced row loads, and describes its keypoints out of LDS, 16 lanes each:
+//   * line requests per frame: 214 tiles x ~390 instead of 2000 keypoints x ~130 (levels 2.. are dense: 20 - 60 keypoints per tile)
+//   * no window registers: the per-row intensity-centroid weights (constant per lane) live in registers instead of being re-read
+//     from LDS for every keypoint, ~70 VGPRs
+//   * tile pitches of 25 / 27 dwords (odd): the 16 lanes of a group read 16 different rows conflict-free in the centroid phase
+// Results are those of k_describe bit for bit (same integer sums, same float expressions, same sample addresses).
+#ifndef DT_W
+#define DT_W 128   // measured on MI355X (profiles/r03_ab_describe.txt): 64 x 64 tiles of 128 threads 0.334 ms, 128 x 64 tiles of 256 threads 0.273 ms
+#endif
+#define DT_H 64
+#define DT_RAW_P ((DT_W + 30 + 7 + 7) & ~7)  // raw tile pitch: DT_W + 30 columns + <= 7 alignment lead-in, 8-byte pieces (104: 26 dwords, the 16
+                                             // rows the lanes of a group read in the centroid phase fall into 16 different banks)
+#define DT_RAW_ROWS (DT_H + 30)
+#define DT_BLR_P ((DT_W + 38 + 7 + 7) & ~7)  // blurred tile pitch: DT_W + 38 columns + <= 7 lead-in (112)
+#define DT_BLR_ROWS (DT_H + 38)
+#ifndef DT_NT
+#define DT_NT 256                    // 16 keypoint groups of 16 lanes
+#endif
+#define DT_CHUNK 512                 // entries of the level's list examined per pass (a 2000-feature level 0 holds 434)
+#define DT_LIST (DT_NT > 160 ? DT_NT : 160)  // keypoints of the tile described per pass (typical: 6 on level 0, 60 on level 7; a sub-pass examines DT_NT records); 7 workgroups per CU
+#define DT_RAW_LD ((DT_RAW_ROWS * (DT_RAW_P / 8) + DT_NT - 1) / DT_NT)   // 8-byte loads per thread: 10
+#define DT_BLR_LD ((DT_BLR_ROWS * (DT_BLR_P / 8) + DT_NT - 1) / DT_NT)   // 12
+
+// rows [ry0, ry0 + NROWS) x 8-byte columns [cx_al, cx_al + 8 NQ) of a level -> registers (tile_issue), then LDS (tile_store): every load
+// of both tiles is in flight before the first store - one global round trip per workgroup.  Rows are clamped into the level,
+// 8-byte columns into the row pitch (clamped data is never sampled: a keypoint keeps edge_threshold >= 19 from the border).
+template <int NROWS, int NQ, int NLD>
+__device__ __forceinline__ void tile_issue(const uint8_t* img, int pitch, int h, int ry0, int cx_al, int tid, uint2 (&v)[NLD]) {
+    const int last_q = (pitch >> 3) - 1;
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+        const int t = min(tid + u * DT_NT, NROWS * NQ - 1), r = t / NQ, c = t - r * NQ;  // (constant divisor)
+        const int y = min(max(ry0 + r, 0), h - 1), q = min(max((cx_al >> 3) + c, 0), last_q);
+        v[u] = ((const uint2*)(img + (size_t)y * pitch))[q];
+    }
+}
+template <int NROWS, int NQ, int NLD>
+__device__ __forceinline__ void tile_store(uint8_t* lds, int tid, const uint2 (&v)[NLD]) {
+#pragma unroll
+    for (int u = 0; u < NLD; u++) {
+        const int t = tid + u * DT_NT, r = t / NQ, c = t - r * NQ;
+        if (t < NROWS * NQ) *(uint2*)(lds + r * (NQ * 8) + 8 * c) = v[u];
+    }
+}
+// rows that are not 8-byte aligned (a caller image whose width is not a multiple of 8): bytes
+__device__ __forceinline__ void tile_load_bytes(const uint8_t* img, int pitch, int w, int h, int ry0, int nrows, int cx0, int lp, uint8_t* lds, int tid) {
+    for (int i = tid; i < nrows * lp; i += DT_NT) {
+        const int r = i / lp, c = i - r * lp;
+        const int y = min(max(ry0 + r, 0), h - 1), x = min(max(cx0 + c, 0), w - 1);
+        lds[i] = img[(size_t)y * pitch + x];
+    }
+}
+
+template <bool HAS_DESC>
+__global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
+                                                          const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                                          const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
+                                                          const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
+                                                          uint8_t* __restrict__ desc, int cap, int* __restrict__ counts, int* flags,
+                                                          const uint32_t* __restrict__ icw) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DT_RAW_ROWS * DT_RAW_P];
+    __shared__ __attribute__((aligned(16))) uint8_t s_blr[HAS_DESC ? DT_BLR_ROWS * DT_BLR_P : 16];
+    __shared__ uint32_t s_list[DT_LIST];  // index in the chunk | dx << 9 | dy << 17
+    __shared__ float2 s_ab[DT_LIST];      // (-, response) -> (angle, -) -> (cos, sin)
+    __shared__ int s_n;
+    int frame = blockIdx.y, tile = blockIdx.x;
+    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, tile);  // XCD affinity (speed only)
+    const uint32_t te = tile_tab[tile];
+    const int L = te & 0xFF;
+    const int x0 = P.lv[L].bx0 + (int)((te >> 8) & 0xFFF) * DT_W, y0 = P.lv[L].by0 + (int)(te >> 20) * DT_H;
+    const int lpitch = P.lv[L].pitch, lbpitch = P.lv[L].bpitch, lw = P.lv[L].w, lh = P.lv[L].h;
+    const float lscale = P.lv[L].scale;
+    const int tid = threadIdx.x, grp = tid / DG, gl = tid % DG;
+    // per-level counts of the frame (wave-uniform, issued together): this level's list length and its first output row
+    const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
+    int total = 0, base = 0, nL = 0;
+    {
+        int cn[MO_MAX_LEVELS];
+#pragma unroll
+        for (int l = 0; l < MO_MAX_LEVELS; l++) cn[l] = fc[l];
+#pragma unroll
+        for (int l = 0; l < MO_MAX_LEVELS; l++) {
+            const int n = l < P.nlevels ? cn[l] : 0;
+            if (l == L) { base = total; nL = n; }
+            total += n;
+        }
+    }
+    if (tile == 0 && tid == 0) {
+        counts[frame] = total;
+        if (total > cap) atomicOr(&flags[0], 2);
+    }
+    nL = min(nL, max(cap - base, 0));  // rows past cap are not produced
+    if (nL == 0) return;               // block-uniform
+    if (tid == 0) s_n = 0;
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    const uint8_t* bl = blur + (size_t)frame * P.blur_stride + P.lv[L].boff;
+    const bool al_raw = (lpitch & 7) == 0 && (((size_t)img) & 7) == 0;
+    const bool al_blr = (((size_t)bl) & 7) == 0;  // (blurred rows have a pitch of a multiple of 16)
+    const int xr_al = al_raw ? (x0 - 15) & ~7 : x0 - 15, lead_r = (x0 - 15) - xr_al;   // raw tile column 0 = level column xr_al
+    const int xb_al = al_blr ? (x0 - 19) & ~7 : x0 - 19;
+    const FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + P.lv[L].fin_off;
+    // ---- everything this workgroup reads from global memory, in flight together: the first chunk of the level's list, both tiles
+    //      (empty tiles are rare: they are loaded unconditionally), the lane's centroid weights and pattern rows
+    FinalKp fk[DT_CHUNK / DT_NT];
+#pragma unroll
+    for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(tid + u * DT_NT, nL - 1)];
+    uint2 vr[DT_RAW_LD], vb[DT_BLR_LD];  // (vb stays unused, and is dropped by the compiler, without descriptors)
+    if (al_raw) tile_issue<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(img, lpitch, lh, y0 - 15, xr_al, tid, vr);
+    if (HAS_DESC && al_blr) tile_issue<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(bl, lbpitch, lh, y0 - 19, xb_al, tid, vb);
+    // the two disc rows of this lane: rows gl and 30 - gl of the 31 (lane 15: row 15 once) have the same half-width, hence the same
+    // weight bytes (u + 16 inside the disc) and mask bytes (1 inside): 16 registers, fetched once per workgroup (the per-keypoint
+    // kernel re-read 32 dwords from LDS for every keypoint).  The lane's 16 pattern rows likewise: 16 registers.
+    uint32_t wt[8], mk[8], pat[16];
+    {
+        const uint4* w = (const uint4*)(icw + gl * 16);
+        const uint4 w0 = w[0], w1 = w[1], k0 = w[2], k1 = w[3];
+        wt[0] = w0.x; wt[1] = w0.y; wt[2] = w0.z; wt[3] = w0.w; wt[4] = w1.x; wt[5] = w1.y; wt[6] = w1.z; wt[7] = w1.w;
+        mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
+        if (HAS_DESC) {
+            const uint4* pp = (const uint4*)(c_pattern + gl * 64);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const uint4 v = pp[q]; pat[4 * q] = v.x; pat[4 * q + 1] = v.y; pat[4 * q + 2] = v.z; pat[4 * q + 3] = v.w; }
+        }
+    }
+    const int row_b_w = gl == 15 ? 0 : 1;  // lane 15's second row is row 15 again: counted once
+    if (al_raw) tile_store<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(s_raw, tid, vr);
+    else tile_load_bytes(img, lpitch, lw, lh, y0 - 15, DT_RAW_ROWS, xr_al, DT_RAW_P, s_raw, tid);
+    if (HAS_DESC) {
+        if (al_blr) tile_store<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(s_blr, tid, vb);
+        else tile_load_bytes(bl, lbpitch, lw, lh, y0 - 19, DT_BLR_ROWS, xb_al, DT_BLR_P, s_blr, tid);
+    }
+    for (int c0 = 0; c0 < nL; c0 += DT_CHUNK) {  // block-uniform trip count (one trip unless a level keeps more than 512 keypoints)
+        if (c0 > 0) {
+#pragma unroll
+            for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(c0 + tid + u * DT_NT, nL - 1)];
+        }
+      // one pass over the chunk's records; a tile that holds more than DT_LIST of them (sub = -1 -> 0) is redone as DT_CHUNK / DT_NT
+      // passes over 128 records each.  Every branch below is block-uniform.
+      for (int sub = -1; sub < DT_CHUNK / DT_NT; sub++) {
+        __syncthreads();  // the previous pass has read the list (first pass: the tile stores above)
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < DT_CHUNK / DT_NT; u++) {
+            const int i = c0 + tid + u * DT_NT;
+            const int dx = (int)fk[u].x - x0, dy = (int)fk[u].y - y0;
+            if ((sub < 0 || u == sub) && i < nL && (unsigned)dx < DT_W && (unsigned)dy < DT_H) {
+                const int pos = atomicAdd(&s_n, 1);
+                if (pos < DT_LIST) {
+                    s_list[pos] = (uint32_t)(i - c0) | ((uint32_t)dx << 9) | ((uint32_t)dy << 17);
+                    s_ab[pos].y = fk[u].response;
+                }
+            }
+        }
+        __syncthreads();
+        const int n = s_n;
+        if (sub < 0 && n > DT_LIST) continue;     // too many for one pass: the sub-passes follow
+        // phase A, 16 lanes per keypoint: intensity-centroid angle, keypoint record; the angle goes into the list
+        for (int j = grp; j < n; j += DT_NT / DG) {  // uniform within a 16-lane group; no barriers inside
+            const uint32_t e = s_list[j];
+            const int i = c0 + (int)(e & 0x1FF), dx = (int)((e >> 9) & 255), dy = (int)(e >> 17);
+            const int k = base + i, x = x0 + dx, y = y0 + dy;
+            // rows gl and 30 - gl of the radius-15 disc on each lane.  A row is read as nine dwords, realigned so that dword c holds
+            // u = 4c - 15 .. 4c - 12, and reduced with two v_dot4_u32_u8 per dword against the row's weight / mask bytes:
+            // sum u p = dot(w) - 16 dot(mask)
+            const int col = dx + lead_r, offr = col & 3;
+            int m10 = 0, m01 = 0;
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int row_i = rr == 0 ? gl : 30 - gl;
+                const uint32_t* rowp = (const uint32_t*)(s_raw + (dy + row_i) * DT_RAW_P + (col & ~3));
+                uint32_t pxw[9];
+#pragma unroll
+                for (int c4 = 0; c4 < 9; c4++) pxw[c4] = rowp[c4];
+                uint32_t sw = 0, rs = 0;
+#pragma unroll
+                for (int c4 = 0; c4 < 8; c4++) {
+                    const uint32_t a = __builtin_amdgcn_alignbyte(pxw[c4 + 1], pxw[c4], (uint32_t)offr);
+                    sw = __builtin_amdgcn_udot4(a, wt[c4], sw, false);
+                    rs = __builtin_amdgcn_udot4(a, mk[c4], rs, false);
+                }
+                const int wgt = rr == 0 ? 1 : row_b_w;
+                m10 += wgt * ((int)sw - 16 * (int)rs);
+                m01 += wgt * (row_i - 15) * (int)rs;
+            }
+            m10 = group_sum(m10);
+            m01 = group_sum(m01);
+            const float angle = fast_atan2_deg((float)m01, (float)m10);
+            if (gl == 0) {
+                mo_keypoint* o = kps + (size_t)frame * cap + k;
+                o->x = (float)x * lscale; o->y = (float)y * lscale;
+                o->size = 31 * lscale;
+                o->angle = angle;
+                o->response = s_ab[j].y;
+                o->octave = L;
+                o->class_id = -1;
+                s_ab[j].x = angle;
+            }
+        }
+        if (HAS_DESC) {
+            __syncthreads();
+            // phase B, ONE lane per keypoint: (float)cos / (float)sin of the angle through f64 as cv2 computes them - once per keypoint
+            // instead of once per lane of its group (the f64 sincos is the longest straight-line piece of the kernel)
+            for (int j = tid; j < n; j += DT_NT) {
+                float angle = s_ab[j].x;
+                angle *= (float)(3.14159265358979323846 / 180.f);
+                double sd, cd;
+                sincos((double)angle, &sd, &cd);
+                s_ab[j] = make_float2((float)cd, (float)sd);
+            }
+            __syncthreads();
+            // phase C, 16 lanes per keypoint: the 256 rotated tests, 16 per lane, out of the blurred tile
+            for (int j = grp; j < n; j += DT_NT / DG) {
+                const uint32_t ex = s_list[j];
+                const int i = c0 + (int)(ex & 0x1FF), dx = (int)((ex >> 9) & 255), dy = (int)(ex >> 17);
+                const int k = base + i;
+                const float px = (float)(x0 + dx) * lscale, py = (float)(y0 + dy) * lscale, inv = 1.f / lscale;
+                const int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
+                const float2 ab = s_ab[j];
+#pragma unroll
+                for (int q = 0; q < 16; q++) asm volatile("" : "+v"(pat[q]));  // opaque per keypoint: the 64 int8 -> float conversions
+                                                                              // stay in the loop instead of being hoisted into 64 registers
+                *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) =
+                    rbrief_u16_reg(s_blr, DT_BLR_P, cx - xb_al, cy - (y0 - 19), ab.x, ab.y, pat);
+            }
+        }
+        if (sub < 0) break;  // the whole chunk went through in one pass
+      }
+    }
+}
+
+static int orb_launch_describe_patch(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
                         int* d_counts) {
     const Plan& P = c->plan;
     const dim3 grid((cap + DK_PER_WG - 1) / DK_PER_WG, batch);
@@ -1419,6 +1675,52 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
     else
         hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
                            d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_lv_tab, inv_per);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+
+int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_counts) {
+    if (c->describe_patch) return orb_launch_describe_patch(c, d_gray, batch, d_kps, d_desc, cap, d_counts);  // VSLAM_AMD_DESCRIBE=patch (A/B timing)
+    const Plan& P = c->plan;
+    if (!c->d_dtile_tab) {  // (re)built with the plan: free_plan_buffers drops it
+        // tile table (level | tile column << 8 | tile row << 20, level-major) followed by the intensity-centroid weights
+        // [32 rows][8 weight + 8 mask dwords]
+        std::vector<uint32_t> tab;
+        for (int L = 0; L < P.nlevels; L++)
+            for (int y = 0; y < (P.lv[L].bh + DT_H - 1) / DT_H; y++)
+                for (int x = 0; x < (P.lv[L].bw + DT_W - 1) / DT_W; x++) tab.push_back((uint32_t)L | ((uint32_t)x << 8) | ((uint32_t)y << 20));
+        c->n_dtiles = (int)tab.size();
+        while (tab.size() % 4) tab.push_back(0);  // the weight rows are read as uint4
+        c->dtile_icw_off = (int)tab.size();
+        tab.resize(tab.size() + 512, 0u);
+        for (int r = 0; r < 31; r++) {
+            const int d = P.umax[r < 15 ? 15 - r : r - 15];
+            for (int c4 = 0; c4 < 8; c4++) {
+                uint32_t wv = 0, mv = 0;
+                for (int b = 0; b < 4; b++) {
+                    const int u = 4 * c4 - 15 + b;
+                    if (u >= -d && u <= d) { wv |= (uint32_t)(u + 16) << (8 * b); mv |= 1u << (8 * b); }
+                }
+                tab[c->dtile_icw_off + r * 16 + c4] = wv;
+                tab[c->dtile_icw_off + r * 16 + 8 + c4] = mv;
+            }
+        }
+        HIPCHK(c, hipMalloc((void**)&c->d_dtile_tab, tab.size() * sizeof(uint32_t)));
+        HIPCHK(c, hipMemcpy(c->d_dtile_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (c->n_dtiles == 0) {  // no level has a border region: every frame has zero keypoints
+        HIPCHK(c, hipMemsetAsync(d_counts, 0, (size_t)batch * sizeof(int), c->stream));
+        return MO_OK;
+    }
+    const dim3 grid(c->n_dtiles, batch);
+    const uint32_t inv_per = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
+    if (d_desc)
+        hipLaunchKernelGGL(k_describe_tiles<true>, grid, dim3(DT_NT), 0, c->stream, P, c->d_dtile_tab, inv_per, d_gray, c->d_pyr, c->d_blur,
+                           c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_dtile_tab + c->dtile_icw_off);
+    else
+        hipLaunchKernelGGL(k_describe_tiles<false>, grid, dim3(DT_NT), 0, c->stream, P, c->d_dtile_tab, inv_per, d_gray, c->d_pyr, c->d_blur,
+                           c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_dtile_tab + c->dtile_icw_off);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
