@@ -623,6 +623,18 @@ def next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K):
         t = time.perf_counter(); ctxf.find_fundamental(p1, p2, 3.0); tsf.append((time.perf_counter() - t) * 1e3)
     legs["find_fundamental_ms"] = {"value": round(sorted(tsf)[len(tsf) // 2], 3), "correspondences": int(len(p1)),
                                    "note": "one pair, host API (H2D + 4096-hypothesis F RANSAC + D2H + sync)"}
+    # the detector Tracker.process_frame really uses (tracker.py:87 -> extract_features(distributed=True) -> extractor.py:85-144):
+    # 8x8 grid of Shi-Tomasi corners + orb.compute at angle -1, as one batched call on the same frames (MO_DETECT_GRID), followed by
+    # the same match + two-view stages
+    pl.io.detector = V.DETECT_GRID
+    elg, stg = timed_calls()
+    legs["grid_mode"] = {"value": round(pl.n * args.steps / elg, 2), "unit": "frames/s", "ms_per_step": round(elg / args.steps * 1e3, 3),
+                         "keypoints_per_frame_mean": float(pl.counts.float().mean().item()),
+                         "matches_per_pair_mean": float(pl.mpass.sum(dim=1).float().mean().item()),
+                         "stage_ms": {k: round(v, 4) for k, v in stg.items()}}
+    pl.io.detector = V.DETECT_ORB
+    pl.launch()  # (the legs below read the ORB keypoints of the headline configuration again)
+    torch.cuda.synchronize()
     return legs
 
 

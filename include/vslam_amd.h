@@ -194,10 +194,22 @@ typedef struct {
     uint64_t pair_index_base; /* global index of this batch's pair 0 when a longer sequence is sharded over calls / ranks: the
                                RANSAC sampling stream of a pair is a function of (seed, global pair index), so the result
                                of a pair does not depend on how the sequence was cut */
+    /* ---- appended in round 3 (optional, zero = rounds 1 - 2 behaviour) ---- */
+    int32_t detector;       /* MO_DETECT_ORB (0): ORBExtractor.detect_and_compute per frame (FAST / pyramid; extractor.py:50-67);
+                               MO_DETECT_GRID (1): ORBExtractor.distribute_keypoints per frame (extractor.py:85-144, what Tracker.process_frame
+                               calls through extract_features(frame), tracker.py:87): 8x8 grid of Shi-Tomasi corners, params->nfeatures / 64
+                               per cell, KeyPoint(x, y, 31) records, orb.compute at angle -1 on octave 0.  d_kps / d_desc / d_counts then
+                               hold the keypoints orb.compute KEEPS (record i = descriptor row i); the reference's own misaligned list
+                               (all corners) is available below */
+    float* d_grid_xy;       /* MO_DETECT_GRID, may be NULL: [batch][64 * (nfeatures / 64)][2] every grid corner, slot (cell, rank) */
+    int32_t* d_grid_n;      /* MO_DETECT_GRID, may be NULL: [batch][66] corners per cell (64), corners in all cells, keypoints kept */
+    int32_t* d_grid_kept;   /* MO_DETECT_GRID, may be NULL: [batch][cap] index of keypoint i in the frame's cell-major corner list */
 } mo_batch_io;
 
 #define MO_MODE_INIT 0
 #define MO_MODE_TRACK 1
+#define MO_DETECT_ORB 0
+#define MO_DETECT_GRID 1
 
 /* One pass of the hot path over a batch: extract every frame, match consecutive frames, two-view pose +
  * map points per pair.  Enqueues on the context stream; call mo_sync (or sync the stream) before reading. */

@@ -28,6 +28,22 @@ def test_struct_layouts():
     assert C.sizeof(V.OrbParams) == 40
 
 
+def test_batch_io_layout_matches_the_header(tmp_path):
+    """sizeof / offsetof of mo_batch_io as a C compiler sees include/vslam_amd.h == the ctypes mirror (fields are appended per round)."""
+    import ctypes as C
+    import subprocess
+    import vslam_amd as V
+    fields = [f[0] for f in V.BatchIO._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vslam_amd.h"\nint main(void) {\n  printf("%zu\\n", sizeof(mo_batch_io));\n' +
+                   "".join('  printf("%%zu\\n", offsetof(mo_batch_io, %s));\n' % f for f in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got[0] == C.sizeof(V.BatchIO)
+    assert got[1:] == [getattr(V.BatchIO, f).offset for f in fields]
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")
 def test_fails_loudly_without_gpu():
     import vslam_amd as V

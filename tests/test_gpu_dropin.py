@@ -367,6 +367,68 @@ def _batch_io(torch, V, dev, frames, nb, cap, n_hyp, pair_base=0, want_mask=Fals
     return io, b, K
 
 
+def test_batched_grid_detector_equals_oracle_on_every_frame():
+    """mo_batch_io.detector = MO_DETECT_GRID: ORBExtractor.distribute_keypoints (reference extractor.py:85-144, the path
+    Tracker.process_frame takes, tracker.py:87) for a whole batch in HBM.  Every frame of a 16-frame batch: all grid corners equal
+    O.grid_good_features, the kept keypoints / their indices / descriptors equal O.compute on KeyPoint(x, y, 31) records, and the
+    match + pose stages run on them (match lists equal the per-pair host call)."""
+    import torch
+    import vslam_amd as V
+    from oracle import orb_oracle as O
+    from tests.helpers import parallax_frames
+    nb, cap, nfeat = 16, 2048, 2000
+    per_cell = nfeat // 64
+    frames = parallax_frames(nb, seed=37)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    try:
+        ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
+        ctx.set_stream(st.cuda_stream)
+        prm = V.orb_params(nfeatures=nfeat)
+        d_fr = torch.from_numpy(frames).to(dev)
+        io, b, K = _batch_io(torch, V, dev, d_fr, nb, cap, 512)
+        gxy = torch.zeros((nb, 64 * per_cell, 2), dtype=torch.float32, device=dev)
+        gn = torch.zeros((nb, 66), dtype=torch.int32, device=dev)
+        gkept = torch.full((nb, cap), -1, dtype=torch.int32, device=dev)
+        io.detector = V.DETECT_GRID
+        io.d_grid_xy = gxy.data_ptr(); io.d_grid_n = gn.data_ptr(); io.d_grid_kept = gkept.data_ptr()
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        st.synchronize()
+        assert ctx.dev_status() == 0
+        assert [n for n, _ in ctx.stage_times()] == ["grid_good_features", "blur", "compute", "match_knn2_ratio", "two_view"]
+        cn = b["counts"].cpu().numpy(); GN = gn.cpu().numpy(); GXY = gxy.cpu().numpy(); GK = gkept.cpu().numpy()
+        kp_np = b["kps"].cpu().numpy().view(np.uint8).reshape(nb, cap, 28)
+        O.lib().orc_set_variant(0, 0)
+        descs = []
+        for f in range(nb):
+            exy = O.grid_good_features(frames[f], nfeat)
+            got = np.concatenate([GXY[f, c * per_cell:c * per_cell + min(GN[f, c], per_cell)] for c in range(64)])
+            assert GN[f, 64] == len(exy) == len(got) and np.array_equal(got, exy), f
+            kin = np.zeros(len(exy), V.KP_DTYPE)
+            kin["x"], kin["y"], kin["size"], kin["angle"], kin["class_id"] = exy[:, 0], exy[:, 1], 31, -1, -1
+            kept, edesc = O.compute(frames[f], O.params(nfeatures=nfeat), kin)
+            n = cn[f]
+            assert n == len(kept) == GN[f, 65] and 300 < n <= len(exy)
+            assert np.array_equal(GK[f, :n], kept), f
+            rec = kp_np[f, :n].reshape(-1).view(V.KP_DTYPE)
+            assert np.array_equal(rec, kin[kept]), f
+            d = b["desc"][f, :n].cpu().numpy()
+            assert np.array_equal(d, edesc), f
+            descs.append(d)
+        host = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+        P = b["pose"].cpu().numpy()
+        for i in range(nb - 1):
+            idx, dist, ps = host.match_knn2_ratio(descs[i], descs[i + 1], 0.75)
+            n = cn[i]
+            assert np.array_equal(b["midx"][i, :n].cpu().numpy(), idx) and np.array_equal(b["mdist"][i, :n].cpu().numpy(), dist)
+            assert np.array_equal(b["mpass"][i, :n].cpu().numpy().astype(bool), ps)
+        assert np.isfinite(P).all(axis=1).sum() >= nb - 2  # unoriented descriptors on a pure pan: nearly every pair gets a pose
+        ctx.close(); host.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
+
+
 def test_bench_workload_all_pairs_properties():
     """BASELINE config 3 + 4 at full size, exactly bench.py's workload (256 frames of its default generator - the SURVEY 8d scene of
     vslam_amd/synth.py - 2000 features, 4096 hypotheses): size-independent properties of EVERY one of the 255 pairs - counts,

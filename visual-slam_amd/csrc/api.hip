@@ -86,6 +86,40 @@ static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray,
     return MO_OK;
 }
 
+// ORBExtractor.distribute_keypoints (reference extractor.py:85-144, the path Tracker.process_frame takes: tracker.py:87) for a whole
+// batch of frames resident in HBM: min-eigenvalue map, the 64 per-cell corner picks, KeyPoint(x, y, 31) records of the corners
+// orb.compute keeps, blur of level 0, descriptors at angle -1 - one launch per step for all frames.  d_kps / d_desc / d_counts receive
+// the KEPT keypoints (record i belongs to descriptor row i, which is what the match / pose stages need); the reference's own list (all
+// corners, misaligned with the rows whenever a corner lies in the border band) is in the optional d_grid_* outputs.
+static int run_grid_extract(mo_ctx* c, const mo_orb_params* p, const mo_batch_io* io) {
+    const int w = io->w, h = io->h, batch = io->batch, cap = io->cap;
+    int rc = mo_build_plan(c, p, w, h, batch);
+    if (rc) return rc;
+    if (p->nfeatures < 64) return mo_fail(c, MO_ERR_ARG, "n_features must be >= 64 (8x8 grid)");
+    if (cap < 1) return mo_fail(c, MO_ERR_ARG, "cap must be >= 1");
+    const int per_cell = p->nfeatures / 64, slots = 64 * per_cell;
+    const size_t B = (size_t)batch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_eig = take(B * w * h * sizeof(float)), o_xy = take(B * slots * 2 * sizeof(float)), o_n = take(B * 66 * sizeof(int));
+    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off))) return rc;
+    uint8_t* b = (uint8_t*)c->d_tmp;
+    float* d_eig = (float*)(b + o_eig);
+    float* d_xy = io->d_grid_xy ? io->d_grid_xy : (float*)(b + o_xy);
+    int* d_n = io->d_grid_n ? io->d_grid_n : (int*)(b + o_n);
+    c->flags_cur = c->d_flags;
+    mo_stage_begin(c);
+    if ((rc = gftt_launch(c, io->d_gray, w, h, p->nfeatures, d_eig, d_xy, d_n, batch))) return rc;
+    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, io->d_kps, io->d_grid_kept, cap, io->d_counts, batch))) return rc;
+    mo_stage_mark(c, "grid_good_features");
+    const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3;
+    if ((rc = orb_launch_blur(c, io->d_gray, batch, 1, blur_margin))) return rc;  // the records all sit on octave 0
+    mo_stage_mark(c, "blur");
+    if ((rc = orb_launch_describe_given(c, io->d_gray, io->d_kps, cap, io->d_desc, io->d_counts, batch, 1))) return rc;
+    mo_stage_mark(c, "compute");
+    return MO_OK;
+}
+
 // copy host images (any stride / 1 or 3 channels) into a dense device gray batch; returns the device pointer
 static int stage_images(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int ch, int batch, const uint8_t** d_gray) {
     if (!img) return mo_fail(c, MO_ERR_ARG, "img is NULL");
@@ -351,10 +385,10 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));
     mo_stage_begin(c);
     if ((rc = gftt_launch(c, d_gray, w, h, n_features, d_eig, d_xy, d_n))) return rc;
-    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, d_rec, d_kept, d_c2))) return rc;
+    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, d_rec, d_kept, slots, nullptr, 1))) return rc;  // (d_c2 = d_n + 64)
     mo_stage_mark(c, "grid_good_features");
     if ((rc = orb_launch_blur(c, d_gray, 1, 1, 0))) return rc;  // the records all sit on octave 0
-    if ((rc = orb_launch_describe_given(c, d_gray, d_rec, slots, d_desc, d_c2 + 1))) return rc;
+    if ((rc = orb_launch_describe_given(c, d_gray, d_rec, slots, d_desc, d_c2 + 1, 1, 0))) return rc;
     mo_stage_mark(c, "compute");
     // everything back through the pinned staging buffer behind one synchronisation
     const size_t h_xy = 16, h_n = h_xy + xy_b, h_kept = h_n + 66 * sizeof(int), h_desc = h_kept + (size_t)slots * sizeof(int32_t);
@@ -723,7 +757,9 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
     if (!c) return MO_ERR_ARG;
     if (!io || !io->d_gray || !io->d_kps || !io->d_desc || !io->d_counts) return mo_fail(c, MO_ERR_ARG, "NULL in mo_batch_io");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, false);
+    if (io->detector != MO_DETECT_ORB && io->detector != MO_DETECT_GRID) return mo_fail(c, MO_ERR_ARG, "mo_batch_io.detector must be MO_DETECT_ORB or MO_DETECT_GRID");
+    int rc = io->detector == MO_DETECT_GRID ? run_grid_extract(c, p, io)
+                                            : run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, false);
     if (rc) return rc;
     int n_pairs = io->batch - 1;
     if (n_pairs < 1 || !io->d_match_idx) return MO_OK;

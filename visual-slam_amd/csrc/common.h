@@ -169,9 +169,10 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
                         int* d_counts);
-int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n = nullptr);
-int gftt_records_launch(mo_ctx* c, const float* d_xy, const int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
-                        int32_t* d_kept, int* d_counts2);
+int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n = nullptr,
+                              int batch = 1, int n_stride = 0);
+int gftt_records_launch(mo_ctx* c, const float* d_xy, int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
+                        int32_t* d_kept, int rec_stride, int32_t* d_counts_out, int batch);
 int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order,
                             int* d_nout);
 // match_kernels.hip
@@ -179,7 +180,7 @@ int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t
                        const int32_t* d_counts, const int32_t* d_qf, const int32_t* d_tf, int nq_fixed, int nt_fixed,
                        int n_pairs, int out_stride, double ratio, int32_t* d_idx, int32_t* d_dist, uint8_t* d_pass);
 // gftt_kernels.hip
-int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, float* d_eig, float* d_xy, int* d_n);
+int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, float* d_eig, float* d_xy, int* d_n, int batch = 1);
 // twoview_kernels.hip
 struct TwoViewArgs {
     int n_pairs, cap, n_hyp;

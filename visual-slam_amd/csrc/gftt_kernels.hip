@@ -22,6 +22,8 @@ __device__ __forceinline__ int gf_reflect101(int p, int len) {
 __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ gray, int w, int h, float* __restrict__ eig) {
     __shared__ float s_dx[(ME_TH + 2) * (ME_TW + 2)], s_dy[(ME_TH + 2) * (ME_TW + 2)];
     const int tx0 = blockIdx.x * ME_TW, ty0 = blockIdx.y * ME_TH, tid = threadIdx.x;
+    gray += (size_t)blockIdx.z * w * h;  // frame of a batch (dense frames, dense maps)
+    eig += (size_t)blockIdx.z * w * h;
     // Dx/Dy are needed at (reflected) coordinates y-1..y+1, x-1..x+1 of the output pixel; each of those needs pixels at
     // its own +-1 (reflected again).  Evaluate them directly from global memory with both reflections (L2-resident).
     const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
@@ -74,6 +76,12 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     __shared__ int s_n;
     __shared__ float s_ax[GF_MAXCORNERS], s_ay[GF_MAXCORNERS];
     const int cell = blockIdx.x, ci = cell / cols, cj = cell - ci * cols;
+    {   // frame of a batch: dense maps, 64 x lim corner slots and 64 + 2 counters per frame
+        const int lim0 = min(max_corners > 0 ? max_corners : GF_MAXCORNERS, GF_MAXCORNERS);
+        eig += (size_t)blockIdx.y * w * h;
+        out_xy += (size_t)blockIdx.y * gridDim.x * lim0 * 2;
+        out_n += (size_t)blockIdx.y * (gridDim.x + 2);
+    }
     const int x0 = cj * cw, y0 = ci * ch, x1 = x0 + cw, y1 = y0 + ch;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // 1. cell maximum (minMaxLoc with the cell mask)
@@ -166,11 +174,13 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     }
 }
 
-int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, float* d_eig, float* d_xy, int* d_n) {
+// batch frames [batch][h][w] -> d_eig [batch][h][w], d_xy [batch][64][per_cell][2], d_n [batch][64 + 2] (the two extra counters
+// per frame are k_gftt_records' totals)
+int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, float* d_eig, float* d_xy, int* d_n, int batch) {
     const int rows = 8, cols = 8, ch = h / rows, cw = w / cols, per_cell = n_features / (rows * cols);
     if (per_cell > GF_MAXCORNERS) return mo_fail(c, MO_ERR_UNSUPPORTED, "more than 256 corners per grid cell");
-    hipLaunchKernelGGL(k_min_eigen, dim3((w + ME_TW - 1) / ME_TW, (h + ME_TH - 1) / ME_TH), dim3(256), 0, c->stream, d_gray, w, h, d_eig);
-    hipLaunchKernelGGL(k_gftt_cell, dim3(rows * cols), dim3(256), 0, c->stream, d_eig, w, h, cols, cw, ch, per_cell, 0.01, 10.0,
+    hipLaunchKernelGGL(k_min_eigen, dim3((w + ME_TW - 1) / ME_TW, (h + ME_TH - 1) / ME_TH, batch), dim3(256), 0, c->stream, d_gray, w, h, d_eig);
+    hipLaunchKernelGGL(k_gftt_cell, dim3(rows * cols, batch), dim3(256), 0, c->stream, d_eig, w, h, cols, cw, ch, per_cell, 0.01, 10.0,
                        d_xy, d_n, c->flags_cur);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
@@ -180,13 +190,21 @@ int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, 
 // orb.compute keeps (Feature2D::compute drops keypoints whose ROUNDED position lies within edge_threshold of the border), in list
 // order, plus their indices in the cell-major list of all corners.  One workgroup: two block scans over <= 64 x per_cell slots.
 // counts2[0] = corners in all cells, counts2[1] = records kept.
-__global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ xy, const int* __restrict__ cell_n, int per_cell, int w,
+// Batched (blockIdx.x = frame): xy / cell_n advance by 64 x per_cell x 2 / 66 per frame, rec / kept by rec_stride records; counts2
+// = cell_n + 64 of the frame; counts_out (may be null) [frame] = records kept (the frame's keypoint count in the batched mode).
+// Records beyond rec_stride are dropped and bit 1 of the flag word is raised (the count still reports the need).
+__global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ xy, int* __restrict__ cell_n, int per_cell, int w,
                                                       int h, int edge, mo_keypoint* __restrict__ rec, int32_t* __restrict__ kept,
-                                                      int* __restrict__ counts2) {
+                                                      int rec_stride, int32_t* __restrict__ counts_out, int* flags) {
     __shared__ int s_base[65];
     __shared__ int s_wsum[4];
     __shared__ int s_run;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    xy += (size_t)blockIdx.x * 64 * per_cell * 2;
+    cell_n += (size_t)blockIdx.x * 66;
+    rec += (size_t)blockIdx.x * rec_stride;
+    if (kept) kept += (size_t)blockIdx.x * rec_stride;
+    int* counts2 = cell_n + 64;
     if (tid == 0) {
         int a = 0;
         for (int cl = 0; cl < 64; cl++) { s_base[cl] = a; a += min(cell_n[cl], per_cell); }
@@ -215,22 +233,27 @@ __global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ 
         int base = s_run;
         for (int k = 0; k < wv; k++) base += s_wsum[k];
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (keep) {
+        if (keep && pos < rec_stride) {
             mo_keypoint kp;
             kp.x = x; kp.y = y; kp.size = 31.f; kp.angle = -1.f; kp.response = 0.f; kp.octave = 0; kp.class_id = -1;
             rec[pos] = kp;
-            kept[pos] = g;
+            if (kept) kept[pos] = g;
         }
         __syncthreads();
         if (tid == 0) s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         __syncthreads();
     }
-    if (tid == 0) { counts2[0] = total; counts2[1] = s_run; }
+    if (tid == 0) {
+        counts2[0] = total; counts2[1] = s_run;
+        if (counts_out) counts_out[blockIdx.x] = s_run;
+        if (s_run > rec_stride) atomicOr(&flags[0], 2);
+    }
 }
 
-int gftt_records_launch(mo_ctx* c, const float* d_xy, const int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
-                        int32_t* d_kept, int* d_counts2) {
-    hipLaunchKernelGGL(k_gftt_records, dim3(1), dim3(256), 0, c->stream, d_xy, d_cell_n, per_cell, w, h, edge, d_rec, d_kept, d_counts2);
+int gftt_records_launch(mo_ctx* c, const float* d_xy, int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
+                        int32_t* d_kept, int rec_stride, int32_t* d_counts_out, int batch) {
+    hipLaunchKernelGGL(k_gftt_records, dim3(batch), dim3(256), 0, c->stream, d_xy, d_cell_n, per_cell, w, h, edge, d_rec, d_kept, rec_stride,
+                       d_counts_out, c->flags_cur);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

@@ -1725,30 +1725,33 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
     return MO_OK;
 }
 
-// compute() with caller keypoints (frame 0 of the context buffers): angle as supplied, level = kp.octave
+// compute() with caller keypoints: angle as supplied, level = kp.octave.  blockIdx.y = frame of a batch (the batched grid detector):
+// records kps + frame * cap, descriptors desc + frame * cap * 32, record count n_dev[frame * n_stride] (n_dev null: n).
 __global__ __launch_bounds__(256) void k_describe_given(Plan P, const uint8_t* __restrict__ gray,
                                                         const uint8_t* __restrict__ pyr, const uint8_t* __restrict__ blur,
                                                         const mo_keypoint* __restrict__ kps, int n, const int* __restrict__ n_dev,
-                                                        uint8_t* __restrict__ desc) {
-    const int lane = threadIdx.x & 63;
+                                                        int n_stride, uint8_t* __restrict__ desc) {
+    const int lane = threadIdx.x & 63, frame = blockIdx.y;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n_dev) n = min(n, *n_dev);  // (the fused grid path: the count of records is only known on the device)
+    const int cap = n;  // records and descriptor rows of a frame are `n` apart
+    if (n_dev) n = min(n, n_dev[(size_t)frame * n_stride]);  // (the count of records is only known on the device)
     if (k >= n) return;
-    mo_keypoint kp = kps[k];
+    mo_keypoint kp = kps[(size_t)frame * cap + k];
     const int L = kp.octave;
     const LevelInfo lv = P.lv[L];
     float inv = 1.f / lv.scale;
     int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
-    const uint8_t* img = level_ptr(P, L, gray, pyr, 0);
-    const uint8_t* bl = blur + lv.boff;
-    rbrief_wave<true>(bl, lv.bpitch, img, lv.pitch, lv.w, lv.h, cx, cy, kp.angle, desc + (size_t)k * 32, lane);
+    const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
+    const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
+    rbrief_wave<true>(bl, lv.bpitch, img, lv.pitch, lv.w, lv.h, cx, cy, kp.angle, desc + ((size_t)frame * cap + k) * 32, lane);
 }
 
-int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n) {
+int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n, int batch,
+                              int n_stride) {
     if (n <= 0) return MO_OK;
     const Plan& P = c->plan;
-    hipLaunchKernelGGL(k_describe_given, dim3((n + 3) / 4), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, d_kps,
-                       n, d_n, d_desc);
+    hipLaunchKernelGGL(k_describe_given, dim3((n + 3) / 4, batch), dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, d_kps,
+                       n, d_n, n_stride, d_desc);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
