@@ -633,7 +633,24 @@ def next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K):
                          "matches_per_pair_mean": float(pl.mpass.sum(dim=1).float().mean().item()),
                          "stage_ms": {k: round(v, 4) for k, v in stg.items()}}
     pl.io.detector = V.DETECT_ORB
-    pl.launch()  # (the legs below read the ORB keypoints of the headline configuration again)
+    # keyframe map growth (LocalMapper._process_new_keyframe, local_mapper.py:116-149; Tracker inserts a keyframe every 20th frame,
+    # tracker.py:290) as one batched call: every 20th frame of the batch paired with the next one - ratio-0.8 match, F-RANSAC (4096
+    # hypotheses, 3 px), triangulation with the two keyframe poses
+    kf = list(range(0, pl.n, 20))
+    q = torch.tensor(kf[:-1], dtype=torch.int32, device=dev); t = torch.tensor(kf[1:], dtype=torch.int32, device=dev)
+    Pm = np.zeros((len(kf), 3, 4)); Pm[:, :, :3] = K
+    for j, f in enumerate(kf):
+        Pm[j, :, 3] = K @ np.array([-0.05 * f, 0.0, 0.0])
+    dP1 = torch.from_numpy(np.ascontiguousarray(Pm[:-1].reshape(-1, 12))).to(dev); dP2 = torch.from_numpy(np.ascontiguousarray(Pm[1:].reshape(-1, 12))).to(dev)
+    pl.io.mode = V.MODE_KEYFRAME; pl.io.ratio = 0.8; pl.io.n_kf_pairs = len(kf) - 1
+    pl.io.d_kf_query = q.data_ptr(); pl.io.d_kf_train = t.data_ptr(); pl.io.d_kf_P1 = dP1.data_ptr(); pl.io.d_kf_P2 = dP2.data_ptr()
+    elk, stk = timed_calls()
+    legs["keyframe_mode"] = {"value": round(pl.n * args.steps / elk, 2), "unit": "frames/s", "ms_per_step": round(elk / args.steps * 1e3, 3),
+                             "keyframe_pairs": len(kf) - 1, "inliers_per_pair_mean": float(pl.npts[:len(kf) - 1].float().mean().item()),
+                             "stage_ms": {k: round(v, 4) for k, v in stk.items()},
+                             "note": "extraction of all %d frames + %d keyframe pairs (every 20th frame) matched, F-RANSAC, triangulated" % (pl.n, len(kf) - 1)}
+    pl.io.mode = V.MODE_INIT; pl.io.ratio = 0.75; pl.io.n_kf_pairs = 0
+    pl.launch()  # (the legs below read the headline configuration's outputs again)
     torch.cuda.synchronize()
     return legs
 

@@ -204,10 +204,24 @@ typedef struct {
     float* d_grid_xy;       /* MO_DETECT_GRID, may be NULL: [batch][64 * (nfeatures / 64)][2] every grid corner, slot (cell, rank) */
     int32_t* d_grid_n;      /* MO_DETECT_GRID, may be NULL: [batch][66] corners per cell (64), corners in all cells, keypoints kept */
     int32_t* d_grid_kept;   /* MO_DETECT_GRID, may be NULL: [batch][cap] index of keypoint i in the frame's cell-major corner list */
+    /* MO_MODE_KEYFRAME (2): LocalMapper._process_new_keyframe (local_mapper.py:116-149) for n_kf_pairs keyframe pairs at once.  The batch's
+     * frames are extracted as usual; pair p matches frame d_kf_query[p] (query, the previous keyframe) against frame d_kf_train[p]
+     * (train, the new keyframe) with `ratio` (the reference passes 0.8) keeping only queries with two neighbours, runs the
+     * fundamental-matrix RANSAC at thr_px (3.0) on the kept matches and triangulates the inliers with the two keyframes' projection
+     * matrices K [R|t] (utils.compute_projection_matrix).  Outputs per PAIR (rows = n_kf_pairs instead of batch - 1): d_match_* ,
+     * d_points [pair][cap][3] by query keypoint (NaN = no map point), d_n_points [pair] = F-RANSAC inliers, d_pose_mask [pair][cap],
+     * d_kf_F [pair][9] (may be NULL; NaN with fewer than 8 matches or no model: the reference returns early in both cases). */
+    int32_t n_kf_pairs;
+    const int32_t* d_kf_query;  /* [n_kf_pairs] frame index of the query keyframe */
+    const int32_t* d_kf_train;  /* [n_kf_pairs] frame index of the train keyframe */
+    const double* d_kf_P1;      /* [n_kf_pairs][12] row-major 3x4 projection matrix of the query keyframe */
+    const double* d_kf_P2;      /* [n_kf_pairs][12] ... of the train keyframe */
+    double* d_kf_F;             /* [n_kf_pairs][9] */
 } mo_batch_io;
 
 #define MO_MODE_INIT 0
 #define MO_MODE_TRACK 1
+#define MO_MODE_KEYFRAME 2
 #define MO_DETECT_ORB 0
 #define MO_DETECT_GRID 1
 

@@ -93,3 +93,72 @@ def test_keyframe_map_growth_like_local_mapper():
     z = pts[:, 2]
     # (keypoints of coarse pyramid levels sit on a 1.2^L pixel grid: their disparities, hence depths, are quantised)
     assert ((np.abs(z - 80) < 25) | (np.abs(z - 40) < 10)).mean() > 0.8
+
+
+def test_batched_keyframe_mode_vs_oracle_per_pair():
+    """MO_MODE_KEYFRAME: LocalMapper._process_new_keyframe (reference local_mapper.py:116-149) for several keyframe pairs of a batch in
+    one call - ratio-0.8 match keeping only queries with two neighbours, F-RANSAC at 3 px, triangulation of the inliers with the
+    caller's two projection matrices.  Per pair: match lists equal the host call, the inlier mask / F equal the oracle's
+    find_fundamental_ransac8 with the pair's own sampling stream, map points equal the oracle's DLT at 1e-4."""
+    import ctypes as C
+    import torch
+    import vslam_amd as V
+    from orbslam2 import utils as geom
+    from tests.helpers import parallax_frames
+    from tests.test_gpu_dropin import _batch_io
+    nb, cap = 12, 2048
+    frames = parallax_frames(nb, seed=41)
+    pairs = [(0, 3), (3, 6), (6, 9), (2, 11), (5, 4)]
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    try:
+        ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
+        ctx.set_stream(st.cuda_stream)
+        prm = V.orb_params(nfeatures=2000)
+        d_fr = torch.from_numpy(frames).to(dev)
+        io, b, K = _batch_io(torch, V, dev, d_fr, nb, cap, 1024, want_mask=True)
+        # keyframe poses: the generator's camera moves 2 px of background parallax per frame along x; any poses do for the DLT
+        poses = []
+        for f in range(nb):
+            T = np.eye(4); T[0, 3] = -0.05 * f
+            poses.append(T)
+        P1 = np.stack([geom.compute_projection_matrix(poses[q][:3, :3], poses[q][:3, 3], K) for q, _ in pairs])
+        P2 = np.stack([geom.compute_projection_matrix(poses[t][:3, :3], poses[t][:3, 3], K) for _, t in pairs])
+        d_q = torch.tensor([q for q, _ in pairs], dtype=torch.int32, device=dev)
+        d_t = torch.tensor([t for _, t in pairs], dtype=torch.int32, device=dev)
+        d_P1 = torch.from_numpy(P1.reshape(len(pairs), 12)).to(dev); d_P2 = torch.from_numpy(P2.reshape(len(pairs), 12)).to(dev)
+        d_F = torch.zeros((len(pairs), 9), dtype=torch.float64, device=dev)
+        io.mode = V.MODE_KEYFRAME; io.ratio = 0.8; io.thr_px = 3.0; io.n_kf_pairs = len(pairs)
+        io.d_kf_query = d_q.data_ptr(); io.d_kf_train = d_t.data_ptr(); io.d_kf_P1 = d_P1.data_ptr(); io.d_kf_P2 = d_P2.data_ptr()
+        io.d_kf_F = d_F.data_ptr(); io.pair_index_base = 100
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        st.synchronize()
+        assert ctx.dev_status() == 0
+        assert [n for n, _ in ctx.stage_times()][-2:] == ["match_knn2_ratio", "keyframe_f_ransac_triangulate"]
+        cn = b["counts"].cpu().numpy()
+        kp = b["kps"].cpu().numpy()
+        host = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+        for p, (q, t) in enumerate(pairs):
+            dq, dt = b["desc"][q, :cn[q]].cpu().numpy(), b["desc"][t, :cn[t]].cpu().numpy()
+            idx, dist, keep = host.match_knn2_ratio(dq, dt, 0.8)
+            assert np.array_equal(b["midx"][p, :cn[q]].cpu().numpy(), idx) and np.array_equal(b["mpass"][p, :cn[q]].cpu().numpy().astype(bool), keep)
+            sel = np.flatnonzero(keep & (idx[:, 1] >= 0))
+            p1 = kp[q, sel, :2].astype(np.float32); p2 = kp[t, idx[sel, 0], :2].astype(np.float32)
+            Fo, mo = G.find_fundamental_ransac8(p1, p2, thr_px=3.0, n_hyp=1024, seed=4096, pair=100 + p)
+            F = d_F[p].cpu().numpy().reshape(3, 3)
+            X = b["pts"][p].cpu().numpy(); mask_q = b["pmask"][p].cpu().numpy().astype(bool)
+            assert Fo is not None and len(sel) > 200
+            assert np.linalg.norm(F - Fo) / np.linalg.norm(Fo) < 1e-4, p
+            got_mask = mask_q[sel]
+            assert (got_mask != mo).sum() <= 2 and not mask_q[np.setdiff1d(np.arange(cap), sel)].any()
+            assert int(b["npts"][p].item()) == int(mask_q.sum())
+            both = got_mask & mo
+            Xo = G.triangulate(P1[p], P2[p], p1[both].astype(np.float64), p2[both].astype(np.float64))
+            Xo = (Xo[:, :3] / Xo[:, 3:4])
+            e = np.linalg.norm(X[sel[both]] - Xo, axis=1) / np.maximum(np.linalg.norm(Xo, axis=1), 1e-9)
+            assert np.median(e) < 1e-5 and e.max() < 1e-3, (p, np.median(e), e.max())  # (float32 output of an ill-conditioned DLT on far points)
+            assert np.isnan(X[~mask_q]).all() and not np.isnan(X[mask_q]).any()
+        ctx.close(); host.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))

@@ -761,9 +761,32 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
     int rc = io->detector == MO_DETECT_GRID ? run_grid_extract(c, p, io)
                                             : run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, false);
     if (rc) return rc;
+    if (io->mode == MO_MODE_KEYFRAME) {
+        // LocalMapper._process_new_keyframe (local_mapper.py:116-149) for n_kf_pairs (query keyframe, train keyframe) pairs of the batch
+        const int np = io->n_kf_pairs;
+        if (np < 1) return MO_OK;
+        if (!io->d_kf_query || !io->d_kf_train || !io->d_kf_P1 || !io->d_kf_P2 || !io->d_match_idx || !io->d_match_dist || !io->d_match_pass ||
+            !io->d_points || !io->d_n_points)
+            return mo_fail(c, MO_ERR_ARG, "MO_MODE_KEYFRAME needs d_kf_query / d_kf_train / d_kf_P1 / d_kf_P2, the match outputs, d_points and d_n_points");
+        if (io->n_hyp < 1) return mo_fail(c, MO_ERR_ARG, "MO_MODE_KEYFRAME needs n_hyp >= 1");
+        rc = match_launch_pairs(c, io->d_desc, io->d_desc, (size_t)io->cap * 32, (size_t)io->cap * 32, io->d_counts, io->d_kf_query, io->d_kf_train,
+                                0, 0, np, io->cap, io->ratio, io->d_match_idx, io->d_match_dist, io->d_match_pass);
+        if (rc) return rc;
+        mo_stage_mark(c, "match_knn2_ratio");
+        TwoViewArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.n_pairs = np; a.cap = io->cap; a.n_hyp = io->n_hyp; a.model = 1;
+        a.K[0] = a.K[4] = a.K[8] = 1.0;
+        a.thr_px = io->thr_px; a.seed = io->seed; a.pair_base = io->pair_index_base;
+        a.d_kps = io->d_kps; a.d_counts = io->d_counts; a.d_match_idx = io->d_match_idx; a.d_match_pass = io->d_match_pass;
+        a.d_qf = io->d_kf_query; a.d_tf = io->d_kf_train; a.need_two = 1; a.d_P1 = io->d_kf_P1; a.d_P2 = io->d_kf_P2;
+        a.d_E = io->d_kf_F; a.d_points = io->d_points; a.d_n_points = io->d_n_points; a.d_inlier = io->d_pose_mask;
+        if ((rc = twoview_launch(c, a))) return rc;
+        mo_stage_mark(c, "keyframe_f_ransac_triangulate");
+        return MO_OK;
+    }
     int n_pairs = io->batch - 1;
     if (n_pairs < 1 || !io->d_match_idx) return MO_OK;
-    if (!io->d_match_dist || !io->d_match_pass) return mo_fail(c, MO_ERR_ARG, "match outputs missing");
     // (query, train) frame of every pair: written once per batch size into a buffer of its own (it was a 5 us launch per call)
     if (c->pair_frames_n < n_pairs) {
         if (c->d_pair_frames) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_pair_frames)); c->d_pair_frames = nullptr; }

@@ -194,6 +194,10 @@ struct TwoViewArgs {
     const int32_t* d_sel; const int32_t* d_sel_n;  // tracking mode: [pairs][cap][2] (queryIdx, trainIdx) in the caller's order + counts;
                                                    // when set, these replace the ratio-test flags as the list of correspondences
     const float* d_p1; const float* d_p2; int m_fixed;  // explicit points (host API): [m][2]
+    const int32_t* d_qf; const int32_t* d_tf;           // keyframe mode: [pairs] query / train frame of each pair (null: pair p = frames p, p + 1)
+    int need_two;                                       // keyframe mode: only queries with a second neighbour take part
+    const double* d_P1; const double* d_P2;             // fundamental model + these ([pairs][12], pixel projection matrices): the inliers are
+                                                        // triangulated with them into d_points (local_mapper.py:148-149)
     const double* d_E_in; const uint8_t* d_mask_in;     // recoverPose on a GIVEN essential matrix ([pairs][9]) and consensus mask
                                                         // ([pairs][cap] by query index, may be null = all): no RANSAC, no refit
     double* d_pose;   // [pairs][12]

@@ -542,8 +542,10 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         tv_f32_copy(a, w, pair, m);
         return;
     }
-    const mo_keypoint* k1 = a.d_kps + (size_t)pair * a.cap;
-    const mo_keypoint* k2 = a.d_kps + (size_t)(pair + 1) * a.cap;
+    // pair p = frame p (query) vs frame p + 1 (train), or the caller's (query frame, train frame) arrays (keyframe mode)
+    const int qfr = a.d_qf ? a.d_qf[pair] : pair, tfr = a.d_tf ? a.d_tf[pair] : pair + 1;
+    const mo_keypoint* k1 = a.d_kps + (size_t)qfr * a.cap;
+    const mo_keypoint* k2 = a.d_kps + (size_t)tfr * a.cap;
     if (a.d_sel) {  // tracking mode: the filtered match list in the reference's order (track_kernels.hip)
         const int m = min(a.d_sel_n[pair], a.cap);
         const int32_t* sl = a.d_sel + (size_t)pair * a.cap * 2;
@@ -560,13 +562,14 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         tv_f32_copy(a, w, pair, m);
         return;
     }
-    // from matcher output: pair p = frame p (query) vs frame p+1 (train); survivors in query order
-    const int nq = min(a.d_counts[pair], a.cap);
+    // from matcher output: survivors of the ratio test in query order (need_two: only queries with a second neighbour,
+    // local_mapper.py:123 `if len(match_pair) >= 2`)
+    const int nq = min(a.d_counts[qfr], a.cap);
     const int32_t* midx = a.d_match_idx + (size_t)pair * a.cap * 2;
     const uint8_t* pass = a.d_match_pass + (size_t)pair * a.cap;
     for (int base = 0; base < nq; base += TV_BLOCK) {
         int i = base + tid;
-        bool ok = i < nq && pass[i];
+        bool ok = i < nq && pass[i] && (!a.need_two || midx[2 * i + 1] >= 0);
         unsigned long long bal = __ballot(ok);
         int lane = tid & 63, wv = tid >> 6;
         int wpre = __popcll(bal & ((1ull << lane) - 1ull));
@@ -1021,7 +1024,19 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
         int cnt = 0;
         for (int i = tid; i < m; i += TVF_BLOCK) {
             const bool in = sampson(Fn, xn[4 * i], xn[4 * i + 1], xn[4 * i + 2], xn[4 * i + 3]) <= thr2;
-            if (in) { cnt++; if (ran_out) ran_out[qidx[i]] = 1; if (inl_out) inl_out[qidx[i]] = 1; }
+            if (in) {
+                cnt++;
+                if (ran_out) ran_out[qidx[i]] = 1;
+                if (inl_out) inl_out[qidx[i]] = 1;
+                if (a.d_P1) {  // keyframe map growth (local_mapper.py:148-149): triangulate the inliers with the caller's two projection matrices
+                    double Pa[12], Pb[12], X[4];
+                    for (int j = 0; j < 12; j++) { Pa[j] = a.d_P1[(size_t)pair * 12 + j]; Pb[j] = a.d_P2[(size_t)pair * 12 + j]; }
+                    dlt_point(Pa, Pb, (double)px[4 * i], (double)px[4 * i + 1], (double)px[4 * i + 2], (double)px[4 * i + 3], X);
+                    const float xf = (float)X[0], yf = (float)X[1], zf = (float)X[2], wf = (float)X[3];
+                    const int o = qidx[i];
+                    Xout[3 * o] = xf / wf; Xout[3 * o + 1] = yf / wf; Xout[3 * o + 2] = zf / wf;
+                }
+            }
         }
         const int total = block_sum_i(cnt, s_redi);
         if (tid == 0) {

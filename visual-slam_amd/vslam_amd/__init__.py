@@ -47,10 +47,12 @@ class BatchIO(C.Structure):
                 ("d_points", C.c_void_p), ("d_n_points", C.c_void_p),
                 ("mode", C.c_int32), ("disp_frac", C.c_double), ("d_sel_idx", C.c_void_p), ("d_sel_dist", C.c_void_p),
                 ("d_sel_n", C.c_void_p), ("d_pose_mask", C.c_void_p), ("pair_index_base", C.c_uint64),
-                ("detector", C.c_int32), ("d_grid_xy", C.c_void_p), ("d_grid_n", C.c_void_p), ("d_grid_kept", C.c_void_p)]
+                ("detector", C.c_int32), ("d_grid_xy", C.c_void_p), ("d_grid_n", C.c_void_p), ("d_grid_kept", C.c_void_p),
+                ("n_kf_pairs", C.c_int32), ("d_kf_query", C.c_void_p), ("d_kf_train", C.c_void_p), ("d_kf_P1", C.c_void_p),
+                ("d_kf_P2", C.c_void_p), ("d_kf_F", C.c_void_p)]
 
 
-MODE_INIT, MODE_TRACK = 0, 1
+MODE_INIT, MODE_TRACK, MODE_KEYFRAME = 0, 1, 2
 DETECT_ORB, DETECT_GRID = 0, 1
 TIMING_SLOTS = 64  # MO_TIMING_SLOTS of the library: event sets kept for Context.stage_times(back)
 
