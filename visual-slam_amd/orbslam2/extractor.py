@@ -68,17 +68,21 @@ class ORBExtractor:
         image = np.asarray(image)
         return keypoints, self.orb.compute(image, keypoints)[1]
 
-    def distribute_keypoints(self, image, n_features=None):
+    def distribute_keypoints(self, image, n_features=None, aligned=False):
         """Grid-based detection (reference extractor.py:85-144): 8x8 cells, Shi-Tomasi corners per cell
         (maxCorners = n_features // 64, qualityLevel 0.01, minDistance 10), KeyPoint(x, y, 31) each, then
         orb.compute on all of them.  Like the reference, the returned list holds ALL corners while the descriptor
-        rows are those cv2 keeps (corners within 31 px of the border are dropped by compute)."""
+        rows are those cv2 keeps (corners within 31 px of the border are dropped by compute).
+        aligned=True (an extension, not in the reference): only the kept corners are returned, so that keypoint i belongs to
+        descriptor row i - what a caller needs to index keypoints with match indices."""
         if n_features is None:
             n_features = self.n_features
         image = np.asarray(image)
         # corners, KeyPoint(x, y, 31) records of the ones orb.compute keeps, and their descriptors in ONE device call
         # (mo_orb_grid_detect_compute: one upload, one synchronisation; the records never exist as Python objects)
         xy, kept, descriptors = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features)
+        if aligned:
+            xy = xy[kept]
         all_keypoints = [KeyPoint(x, y, 31) for x, y in xy.tolist()]  # (tolist: Python floats at once, not a numpy scalar per field)
         if not len(kept):
             descriptors = None
