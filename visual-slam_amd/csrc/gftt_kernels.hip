@@ -14,64 +14,100 @@ __device__ __forceinline__ int gf_reflect101(int p, int len) {
     return p;
 }
 
-#define ME_TW 32
-#define ME_TH 8
+#define ME_TW 64
+#define ME_TH 16
 
 // cornerMinEigenVal(blockSize 3, Sobel 3, BORDER_REFLECT_101): u8 tile (+2 halo) -> Dx, Dy (+1 halo) -> 3x3 box of the
-// covariance terms in f64 -> (a + c) - sqrt((a - c)^2 + b^2)
+// covariance terms in f64 -> (a + c) - sqrt((a - c)^2 + b^2).  Round 3: the pixel tile goes through LDS once (one byte load per
+// tile pixel; rounds 1 - 2 read nine reflected bytes from global memory per gradient sample: 0.49 ms per 256 frames, now bound by
+// its arithmetic); same float expressions in the same order.
 __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ gray, int w, int h, float* __restrict__ eig) {
+    __shared__ uint8_t s_px[(ME_TH + 4) * (ME_TW + 4)];
     __shared__ float s_dx[(ME_TH + 2) * (ME_TW + 2)], s_dy[(ME_TH + 2) * (ME_TW + 2)];
     const int tx0 = blockIdx.x * ME_TW, ty0 = blockIdx.y * ME_TH, tid = threadIdx.x;
     gray += (size_t)blockIdx.z * w * h;  // frame of a batch (dense frames, dense maps)
     eig += (size_t)blockIdx.z * w * h;
-    // Dx/Dy are needed at (reflected) coordinates y-1..y+1, x-1..x+1 of the output pixel; each of those needs pixels at
-    // its own +-1 (reflected again).  Evaluate them directly from global memory with both reflections (L2-resident).
+    // s_px[r][c] = pixel at (reflect(reflect(ty0 + r' - 1) + dr), ...) is NOT separable into one reflection of ty0 + r - 2: the Sobel
+    // window of a reflected gradient position is reflected again.  Away from the image border both agree, so interior tiles stage
+    // plain coordinates and border tiles (block-uniform test) keep the double reflection through an index table per axis.
+    const bool interior = tx0 >= 2 && ty0 >= 2 && tx0 + ME_TW + 2 <= w && ty0 + ME_TH + 2 <= h;
     const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float f1 = (float)(1.0f * scale_d), f0 = (float)(2.0f * scale_d);
-    for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
-        int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
-        int y = gf_reflect101(ty0 + r - 1, h), x = gf_reflect101(tx0 + c - 1, w);
-        const uint8_t* rm = gray + (size_t)gf_reflect101(y - 1, h) * w;
-        const uint8_t* r0 = gray + (size_t)y * w;
-        const uint8_t* rp = gray + (size_t)gf_reflect101(y + 1, h) * w;
-        int xm = gf_reflect101(x - 1, w), xp = gf_reflect101(x + 1, w);
-        float Rm = (float)((int)rm[xp] - (int)rm[xm]), R0 = (float)((int)r0[xp] - (int)r0[xm]),
-              Rp = (float)((int)rp[xp] - (int)rp[xm]);
-        float t = Rm + Rp;
-        float u = t * f1;
-        float v = R0 * f0;
-        s_dx[i] = u + v;
-        float Cm = ((f1 * (float)rm[xm]) + f0 * (float)rm[x]) + f1 * (float)rm[xp];
-        float Cp = ((f1 * (float)rp[xm]) + f0 * (float)rp[x]) + f1 * (float)rp[xp];
-        s_dy[i] = Cp - Cm;
+    if (interior) {
+        for (int i = tid; i < (ME_TH + 4) * (ME_TW + 4); i += 256) {
+            const int r = i / (ME_TW + 4), c = i - r * (ME_TW + 4);
+            s_px[i] = gray[(size_t)(ty0 + r - 2) * w + tx0 + c - 2];
+        }
+        __syncthreads();
+        for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
+            const int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
+            const uint8_t* rm = s_px + r * (ME_TW + 4) + c;        // rows y - 1, y, y + 1 of the gradient position, columns x - 1 .. x + 1
+            const uint8_t* r0 = rm + (ME_TW + 4);
+            const uint8_t* rp = r0 + (ME_TW + 4);
+            float Rm = (float)((int)rm[2] - (int)rm[0]), R0 = (float)((int)r0[2] - (int)r0[0]), Rp = (float)((int)rp[2] - (int)rp[0]);
+            float t = Rm + Rp;
+            float u = t * f1;
+            float v = R0 * f0;
+            s_dx[i] = u + v;
+            float Cm = ((f1 * (float)rm[0]) + f0 * (float)rm[1]) + f1 * (float)rm[2];
+            float Cp = ((f1 * (float)rp[0]) + f0 * (float)rp[1]) + f1 * (float)rp[2];
+            s_dy[i] = Cp - Cm;
+        }
+    } else {
+        // Dx/Dy are needed at (reflected) coordinates y-1..y+1, x-1..x+1 of the output pixel; each of those needs pixels at
+        // its own +-1 (reflected again): evaluated directly from global memory with both reflections
+        for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
+            int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
+            int y = gf_reflect101(ty0 + r - 1, h), x = gf_reflect101(tx0 + c - 1, w);
+            const uint8_t* rm = gray + (size_t)gf_reflect101(y - 1, h) * w;
+            const uint8_t* r0 = gray + (size_t)y * w;
+            const uint8_t* rp = gray + (size_t)gf_reflect101(y + 1, h) * w;
+            int xm = gf_reflect101(x - 1, w), xp = gf_reflect101(x + 1, w);
+            float Rm = (float)((int)rm[xp] - (int)rm[xm]), R0 = (float)((int)r0[xp] - (int)r0[xm]),
+                  Rp = (float)((int)rp[xp] - (int)rp[xm]);
+            float t = Rm + Rp;
+            float u = t * f1;
+            float v = R0 * f0;
+            s_dx[i] = u + v;
+            float Cm = ((f1 * (float)rm[xm]) + f0 * (float)rm[x]) + f1 * (float)rm[xp];
+            float Cp = ((f1 * (float)rp[xm]) + f0 * (float)rp[x]) + f1 * (float)rp[xp];
+            s_dy[i] = Cp - Cm;
+        }
     }
     __syncthreads();
-    const int lx = tid & 31, ly = tid >> 5;
-    const int x = tx0 + lx, y = ty0 + ly;
-    if (x >= w || y >= h) return;
-    double sxx = 0, sxy = 0, syy = 0;
+    const int lx = tid & 63;
+    for (int ly = tid >> 6; ly < ME_TH; ly += 4) {
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= w || y >= h) continue;
+        double sxx = 0, sxy = 0, syy = 0;
 #pragma unroll
-    for (int j = 0; j < 3; j++)
+        for (int j = 0; j < 3; j++)
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-            float a = s_dx[(ly + j) * (ME_TW + 2) + lx + i], b = s_dy[(ly + j) * (ME_TW + 2) + lx + i];
-            float xx = a * a, xy = a * b, yy = b * b;
-            sxx += (double)xx; sxy += (double)xy; syy += (double)yy;
-        }
-    float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-    float amc = a - c;
-    float rad = amc * amc + b * b;
-    eig[(size_t)y * w + x] = (a + c) - sqrtf(rad);
+            for (int i = 0; i < 3; i++) {
+                float a = s_dx[(ly + j) * (ME_TW + 2) + lx + i], b = s_dy[(ly + j) * (ME_TW + 2) + lx + i];
+                float xx = a * a, xy = a * b, yy = b * b;
+                sxx += (double)xx; sxy += (double)xy; syy += (double)yy;
+            }
+        float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+        float amc = a - c;
+        float rad = amc * amc + b * b;
+        eig[(size_t)y * w + x] = (a + c) - sqrtf(rad);
+    }
 }
 
 #define GF_CAP 4096       // local maxima per cell held in LDS
 #define GF_MAXCORNERS 256
 
-// one workgroup per grid cell
+#define GF_TILE_MAX 5248  // floats of the cell + 1-px ring held in LDS ((80 + 2) x (60 + 2) = 5084 at 640 x 480); larger cells read the map from global memory
+#define GF_TILE_KEYS (GF_CAP - GF_TILE_MAX / 2)  // the tile lives in the upper part of the key array: keys [0, 1472) may be filled while it is in use
+
+// one workgroup per grid cell (blockIdx.y = frame of a batch)
 __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig, int w, int h, int cols, int cw, int ch,
                                                    int max_corners, double quality, double min_dist, float* __restrict__ out_xy,
                                                    int* __restrict__ out_n, int* flags) {
     __shared__ unsigned long long s_key[GF_CAP];
+    float* const s_tile = (float*)(s_key + GF_TILE_KEYS);  // dead once the candidates are listed; a cell with more than GF_TILE_KEYS
+                                                           // local maxima (typical: 300) lists them again from global memory
     __shared__ float s_red[4];
     __shared__ int s_n;
     __shared__ float s_ax[GF_MAXCORNERS], s_ay[GF_MAXCORNERS];
@@ -84,15 +120,26 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     }
     const int x0 = cj * cw, y0 = ci * ch, x1 = x0 + cw, y1 = y0 + ch;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // the cell and its 1-px ring (clamped into the image: ring positions outside it are never read) go through LDS once; rounds 1 - 2
+    // read the map from global memory up to ten times per pixel (maximum, threshold, 3x3 dilation)
+    const int tw = cw + 2, th = ch + 2;
+    const bool in_lds = tw * th <= GF_TILE_MAX;  // block-uniform
+    if (in_lds)
+        for (int i = tid; i < tw * th; i += 256) {
+            const int r = i / tw, c = i - r * tw;
+            const int yy = min(max(y0 - 1 + r, 0), h - 1), xx = min(max(x0 - 1 + c, 0), w - 1);
+            s_tile[i] = eig[(size_t)yy * w + xx];
+        }
+    if (tid == 0) s_n = 0;
+    __syncthreads();
     // 1. cell maximum (minMaxLoc with the cell mask)
     float m = -FLT_MAX;
     for (int i = tid; i < cw * ch; i += 256) {
-        int yy = y0 + i / cw, xx = x0 + i % cw;
-        m = fmaxf(m, eig[(size_t)yy * w + xx]);
+        const int r = i / cw, c = i - r * cw;
+        m = fmaxf(m, in_lds ? s_tile[(r + 1) * tw + c + 1] : eig[(size_t)(y0 + r) * w + x0 + c]);
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) s_red[wv] = m;
-    if (tid == 0) s_n = 0;
     __syncthreads();
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     const double maxVal = m > 0 ? (double)m : 0.0;
@@ -100,24 +147,48 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     // 2. candidates: above threshold (THRESH_TOZERO) and equal to the 3x3 dilation of the thresholded map
     const int ya = max(y0, 1), yb = min(y1, h - 1), xa = max(x0, 1), xb = min(x1, w - 1);
     const int cw2 = xb - xa, n_in = cw2 > 0 && yb > ya ? cw2 * (yb - ya) : 0;
-    for (int i = tid; i < n_in; i += 256) {
-        int yy = ya + i / cw2, xx = xa + i % cw2;
-        const float* p = eig + (size_t)yy * w + xx;
-        float v = p[0];
-        if (!(v > thr)) continue;
-        float mx = v;
+    for (int pass = in_lds ? 0 : 1; pass < 2; pass++) {  // pass 0: out of the LDS tile; pass 1: from global memory (block-uniform)
+        const int key_cap = pass == 0 ? GF_TILE_KEYS : GF_CAP;
+        for (int i = tid; i < n_in; i += 256) {
+            int yy = ya + i / cw2, xx = xa + i % cw2;
+            float v, mx;
+            if (pass == 0) {
+                const float* p = s_tile + (yy - y0 + 1) * tw + (xx - x0 + 1);
+                v = p[0];
+                if (!(v > thr)) continue;
+                mx = v;
 #pragma unroll
-        for (int j = -1; j <= 1; j++)
+                for (int j = -1; j <= 1; j++)
 #pragma unroll
-            for (int k = -1; k <= 1; k++) {
-                float q = p[j * w + k];
-                q = q > thr ? q : 0.f;
-                mx = fmaxf(mx, q);
+                    for (int k = -1; k <= 1; k++) {
+                        float q = p[j * tw + k];
+                        q = q > thr ? q : 0.f;
+                        mx = fmaxf(mx, q);
+                    }
+            } else {
+                const float* p = eig + (size_t)yy * w + xx;
+                v = p[0];
+                if (!(v > thr)) continue;
+                mx = v;
+#pragma unroll
+                for (int j = -1; j <= 1; j++)
+#pragma unroll
+                    for (int k = -1; k <= 1; k++) {
+                        float q = p[j * w + k];
+                        q = q > thr ? q : 0.f;
+                        mx = fmaxf(mx, q);
+                    }
             }
-        if (v == mx) {
-            int slot = atomicAdd(&s_n, 1);
-            if (slot < GF_CAP) s_key[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx);
+            if (v == mx) {
+                int slot = atomicAdd(&s_n, 1);
+                if (slot < key_cap) s_key[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx);
+            }
         }
+        __syncthreads();
+        if (pass == 1 || s_n <= GF_TILE_KEYS) break;  // (block-uniform)
+        __syncthreads();
+        if (tid == 0) s_n = 0;  // more local maxima than fit beside the tile: list them again without it
+        __syncthreads();
     }
     __syncthreads();
     int n = s_n;
@@ -142,33 +213,49 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
             }
             __syncthreads();
         }
-    // 4. greedy minimum-distance pick by one wavefront (candidates in sorted order, accepted corners on the lanes)
+    // 4. greedy minimum-distance pick by one wavefront, 64 candidates of the sorted list at a time, one per lane: a lane first
+    //    drops its candidate if it lies within min_dist of a corner accepted in earlier batches, then the surviving lanes are
+    //    resolved in list order - the lowest one is accepted and knocks out the later lanes within min_dist of it.  The accepted
+    //    set and its order are those of the sequential loop (a candidate is accepted iff no EARLIER accepted corner is near).
     if (wv == 0) {
         const float md2 = (float)(min_dist * min_dist);
+        const bool use_dist = min_dist >= 1.0;
         int nacc = 0;
         const int lim = min(max_corners > 0 ? max_corners : GF_MAXCORNERS, GF_MAXCORNERS);
-        for (int i = 0; i < n && nacc < lim; i++) {
-            unsigned pos = (unsigned)(s_key[i] & 0xFFFFFFFFull);
-            int yy = pos / w, xx = pos - yy * w;
-            bool bad = false;
-            if (min_dist >= 1.0)
-                for (int jb = 0; jb < nacc; jb += 64) {
-                    int j = jb + lane;
-                    bool near = false;
-                    if (j < nacc) {
-                        float dx = (float)xx - s_ax[j], dy = (float)yy - s_ay[j];
-                        near = dx * dx + dy * dy < md2;
+        for (int i0 = 0; i0 < n && nacc < lim; i0 += 64) {  // wave-uniform
+            const int i = i0 + lane;
+            bool alive = i < n;
+            float fx = 0.f, fy = 0.f;
+            if (alive) {
+                const unsigned pos = (unsigned)(s_key[i] & 0xFFFFFFFFull);
+                const int yy = pos / w, xx = pos - yy * w;
+                fx = (float)xx; fy = (float)yy;
+                if (use_dist)
+                    for (int j = 0; j < nacc; j++) {  // accepted corners: wave-uniform LDS reads (broadcast)
+                        const float dx = fx - s_ax[j], dy = fy - s_ay[j];
+                        if (dx * dx + dy * dy < md2) { alive = false; break; }
                     }
-                    bad = bad || __any(near);
-                }
-            if (!bad) {
+            }
+            unsigned long long live = __ballot(alive);
+            while (live && nacc < lim) {  // wave-uniform
+                const int l = __ffsll((long long)live) - 1;
+                const float ax = __shfl(fx, l, 64), ay = __shfl(fy, l, 64);
                 if (lane == 0) {
-                    s_ax[nacc] = (float)xx; s_ay[nacc] = (float)yy;
-                    out_xy[((size_t)cell * lim + nacc) * 2] = (float)xx;
-                    out_xy[((size_t)cell * lim + nacc) * 2 + 1] = (float)yy;
+                    s_ax[nacc] = ax; s_ay[nacc] = ay;
+                    out_xy[((size_t)cell * lim + nacc) * 2] = ax;
+                    out_xy[((size_t)cell * lim + nacc) * 2 + 1] = ay;
                 }
                 nacc++;
+                if (lane == l) alive = false;
+                else if (alive && use_dist) {
+                    const float dx = fx - ax, dy = fy - ay;
+                    if (dx * dx + dy * dy < md2) alive = false;
+                }
+                live = __ballot(alive);
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_ax / s_ay written by lane 0 are read by all lanes in the next batch
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         if (lane == 0) out_n[cell] = nacc;
     }

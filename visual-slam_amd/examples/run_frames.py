@@ -48,14 +48,15 @@ def load_config(path):
     if path:
         with open(path) as f:
             user = yaml.safe_load(f) or {}
+        ucam = user.get("camera", {}) or {}
+        if "camera_matrix" not in ucam or "distortion_coeffs" not in ucam:   # utils.py:31-32 of the reference
+            raise KeyError("'camera_matrix' or 'distortion_coeffs' missing in 'camera' section of config")
         for k, v in user.items():
             if isinstance(v, dict) and isinstance(cfg.get(k), dict):
                 cfg[k].update(v)
             else:
                 cfg[k] = v
     cam = cfg["camera"]
-    if "camera_matrix" not in cam or "distortion_coeffs" not in cam:
-        raise KeyError("'camera_matrix' or 'distortion_coeffs' missing in 'camera' section of config")
     K = np.array(cam["camera_matrix"], dtype=float).reshape(3, 3)
     D = np.array(cam["distortion_coeffs"], dtype=float)
     return cfg, K, D
