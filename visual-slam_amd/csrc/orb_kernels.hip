@@ -603,20 +603,27 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
         const int pos = r * SW + x;
         // flip (wave-uniform) = 0xFF: brighter-arc polarity, bytes complemented: (255 - v) - (255 - p) = p - v
         lds_cvu8* p = (lds_cvu8*)&s_tile[(r + 3) * TW + x + 3 + lead];
-        const int v = (int)p[0] ^ flip;
+        // d = centre - circle pixel for BOTH polarities: the brighter-arc score max over arcs of min9(-d) = -(min over arcs of max9(d)) runs
+        // the same network with min and max exchanged (flip is a constant at every call site) and negates the result, instead of
+        // complementing all 17 pixels.  (Written as plain 16-bit C the compiler fuses pairs into v_min3 / v_max3_i16, which issue at
+        // half rate: 0.785 against 0.735 ms per 256 frames, profiles/r03_ab_fast16.txt - hence the VOP2 forms by inline asm.)
+        const int v = (int)p[0];
         int d[16];
-#define FAST_D(k, o) d[k] = sub16(v, (int)p[o] ^ flip);
+#define FAST_D(k, o) d[k] = sub16(v, (int)p[o]);
         FAST_D(0, 3 * TW)        FAST_D(1, 3 * TW + 1)    FAST_D(2, 2 * TW + 2)    FAST_D(3, TW + 3)
         FAST_D(4, 3)             FAST_D(5, -TW + 3)       FAST_D(6, -2 * TW + 2)   FAST_D(7, -3 * TW + 1)
         FAST_D(8, -3 * TW)       FAST_D(9, -3 * TW - 1)   FAST_D(10, -2 * TW - 2)  FAST_D(11, -TW - 3)
         FAST_D(12, -3)           FAST_D(13, TW - 3)       FAST_D(14, 2 * TW - 2)   FAST_D(15, 3 * TW - 1)
 #undef FAST_D
+        auto lo = [flip](int a, int b2) { return flip ? max16(a, b2) : min16(a, b2); };
+        auto hi = [flip](int a, int b2) { return flip ? min16(a, b2) : max16(a, b2); };
         int mn3[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) mn3[i] = min16(d[i], min16(d[(i + 1) & 15], d[(i + 2) & 15]));
-        int L = min16(mn3[0], min16(mn3[3], mn3[6]));
+        for (int i = 0; i < 16; i++) mn3[i] = lo(d[i], lo(d[(i + 1) & 15], d[(i + 2) & 15]));
+        int Ls = lo(mn3[0], lo(mn3[3], mn3[6]));
 #pragma unroll
-        for (int i = 1; i < 16; i++) L = max16(L, min16(mn3[i], min16(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
+        for (int i = 1; i < 16; i++) Ls = hi(Ls, lo(mn3[i], lo(mn3[(i + 3) & 15], mn3[(i + 6) & 15])));
+        const int L = flip ? -(int)(short)Ls : (int)(short)Ls;
         const int b = (int)(short)L;
         if (own && b > t) s_score[pos] = (uint8_t)(b - 1);  // the band is zero-filled; the other polarity of the pixel writes nothing
         // list the corners for phase 3 (order is irrelevant): one LDS atomic per wavefront call
@@ -907,7 +914,10 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
         const int grp = tid / HG, g = tid % HG;
         // HB keypoints per group and trip: all their window loads are issued before the first one is reduced - the phase is a
         // chain of global-load latencies (1.5 us per keypoint when taken one at a time), not of work
-        constexpr int HB = 4;
+#ifndef SEL_HB
+#define SEL_HB 4
+#endif
+        constexpr int HB = SEL_HB;
         for (int i0 = 0; i0 < N1; i0 += HG_GROUPS * HB) {  // block-uniform trip count (the shuffles want whole wavefronts)
             uint32_t e[HB], reg[HB][4];
 #pragma unroll
