@@ -203,7 +203,9 @@ def main():
     torch.cuda.synchronize()
     main_s = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(main_s)
-    use_rccl = world > 1 and args.backend == "nccl"  # the gather goes through the library's own RCCL entry point
+    # N > 1 under RCCL: the gather goes through the library's own entry point (mo_comm_init / mo_gather_map_points); if that
+    # communicator cannot be set up on some rank, every rank falls back to torch.distributed's gather (agreed by an all-reduce)
+    rccl = {"on": world > 1 and args.backend == "nccl"}
 
     class Pipeline:
         """This rank's context, input frames and output buffers for nb frames (n_pairs = nb - 1 consecutive pairs)."""
@@ -253,7 +255,7 @@ def main():
             self.pl, self.B, self.n_pairs, self.pairs_all = pl, B, n_pairs, pairs_all
             self.k = 0
             self.pending = [None, None]
-            if use_rccl:
+            if rccl["on"]:
                 self.comm_s = torch.cuda.Stream(device=dev)
                 self.done = [torch.cuda.Event(), torch.cuda.Event()]
                 self.all = torch.zeros((world, B, CAP, 3), dtype=torch.float32, device=dev) if rank == 0 else None
@@ -277,7 +279,7 @@ def main():
             k = self.k
             self.k ^= 1
             buf = self.pl.pts[k]
-            if use_rccl:
+            if rccl["on"]:
                 self.comm_s.wait_stream(main_s)
                 ctx = self.pl.ctx
                 ctx.set_stream(self.comm_s.cuda_stream)
@@ -287,7 +289,8 @@ def main():
                 self.done[k].record(self.comm_s)
                 self.pending[k] = "rccl"
             else:
-                self.pending[k] = gather_map_points(buf.cpu(), self.n_pairs, dst=0, pairs_per_rank=self.pairs_all, async_op=True)
+                self.pending[k] = gather_map_points(buf if args.backend == "nccl" else buf.cpu(), self.n_pairs, dst=0,
+                                                    pairs_per_rank=self.pairs_all, async_op=True)
             if args.sync_gather:
                 self.finish(k)
 
@@ -308,11 +311,25 @@ def main():
             if cache:
                 np.save(cache, frames.cpu().numpy())
         pl = Pipeline(frames, first_pair, B)
-        ga = Gather(pl, B, n_pairs, pairs_all) if world > 1 else None
-        if use_rccl:
-            ids = [V.Context.comm_unique_id() if rank == 0 else None]
+        if rccl["on"]:
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids[0] = V.Context.comm_unique_id()
+                except Exception as e:
+                    print("mo_comm_unique_id failed (%s): falling back to torch.distributed.gather" % e, file=sys.stderr)
             dist.broadcast_object_list(ids, src=0)
-            pl.ctx.comm_init(ids[0], rank, world)
+            ok = 0
+            if ids[0] is not None:
+                try:
+                    pl.ctx.comm_init(ids[0], rank, world)
+                    ok = 1
+                except Exception as e:
+                    print("rank %d: mo_comm_init failed (%s)" % (rank, e), file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            rccl["on"] = bool(int(flag.item()))
+        ga = Gather(pl, B, n_pairs, pairs_all) if world > 1 else None
 
         def step():
             if ga:
@@ -354,7 +371,7 @@ def main():
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
-        if use_rccl and rank == 0:  # the gathered slabs are what the ranks computed: row counts and rank 0's own slab
+        if rccl["on"] and rank == 0:  # the gathered slabs are what the ranks computed: row counts and rank 0's own slab
             assert ga.rows_all.cpu().tolist() == pairs_all, (ga.rows_all.cpu().tolist(), pairs_all)
             k_last = ga.k ^ 1
             a, b = ga.all[0, :n_pairs], pl.pts[k_last][:n_pairs]
@@ -427,10 +444,10 @@ def main():
                        "frames_per_gpu": B, "n_features": NFEAT, "hypotheses": N_HYP,
                        "keypoints_per_frame_mean": float(cnt.mean()), "matches_per_pair_mean": mpass_mean,
                        "map_points_per_pair_mean": float(npt.mean()),
-                       "parallelism": "frame-sharded x%d, %s" % (world, "RCCL gather of map points through mo_gather_map_points" if use_rccl
+                       "parallelism": "frame-sharded x%d, %s" % (world, "RCCL gather of map points through mo_gather_map_points" if rccl["on"]
                                                                  else "gather of map points (torch.distributed %s)" % args.backend if world > 1
                                                                  else "single GPU"),
-                       "rccl_ranks": world if use_rccl else 0},
+                       "rccl_ranks": world if rccl["on"] else 0},
             "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM_GBPS, 5), "hbm_frac": round(achieved / PEAK_HBM_GBPS, 5),
                          "valu_frac": round(valu_frac, 4) if valu_frac else None, "traffic": traffic,
