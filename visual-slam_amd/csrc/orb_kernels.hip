@@ -1261,21 +1261,29 @@ __device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch,
     return (uint16_t)val;  // little endian: bits 0..7 = byte 2gl, bits 8..15 = byte 2gl+1
 }
 
-// The same 16 tests per lane with the lane's pattern rows held in registers (pat[k] = x0 | y0 << 8 | x1 << 16 | y1 << 24 as int8
-// of test 16 gl + k): the tile kernel describes many keypoints per lane, so the table is fetched once per workgroup.
-__device__ __forceinline__ uint16_t rbrief_u16_reg(const uint8_t* patch, int ppitch, int cx, int cy, float a, float b, const uint32_t (&pat)[16]) {
-    const int cxm = cx - 0x4B400000, cym = cy - 0x4B400000;
-    unsigned val = 0;
+// The same 16 tests per lane for the tile kernel.  pat: the pattern as floats in LDS, test-major interleaved so that the 16 lanes
+// of a group read 16 consecutive float4 rows per test (conflict-free ds_read_b128, the four groups of a wavefront read the same rows:
+// broadcast) - no int8 -> float conversion per keypoint (64 half-rate v_cvt per lane before).  lds_base: LDS byte address of the
+// sample (cx, cy) of the blurred tile; the sample address is ONE v_mad_i32_i24 per point: the rounding bias 0x4B400000 of jx and its
+// low 24 bits 0x400000 of jy (x pitch) are folded into the base.  A test bit is the sign of t0 - t1 shifted in by v_alignbit.
+typedef const __attribute__((address_space(3))) uint8_t lds_cu8;
+__device__ __forceinline__ uint16_t rbrief_u16_lds(uint32_t lds_base, int ppitch, float a, float b, const float4* pat, int gl) {
+    const uint32_t base = lds_base - 0x4B400000u - 0x400000u * (uint32_t)ppitch;
+    uint32_t val = 0;
+#ifndef RB_UNROLL
+#define RB_UNROLL 16
+#endif
+#pragma unroll 1
+    for (int k0 = 16 - RB_UNROLL; k0 >= 0; k0 -= RB_UNROLL) {  // RB_UNROLL tests per trip (16: fully unrolled; the register peak of the kernel lies elsewhere)
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t pk = pat[k];
-        const float fx0 = (float)(int8_t)(pk & 0xFF), fy0 = (float)(int8_t)((pk >> 8) & 0xFF);
-        const float fx1 = (float)(int8_t)((pk >> 16) & 0xFF), fy1 = (float)(int8_t)(pk >> 24);
-        const int jx0 = __float_as_int((fx0 * a - fy0 * b) + 12582912.f), jy0 = __float_as_int((fx0 * b + fy0 * a) + 12582912.f);
-        const int jx1 = __float_as_int((fx1 * a - fy1 * b) + 12582912.f), jy1 = __float_as_int((fx1 * b + fy1 * a) + 12582912.f);
-        const int t0 = patch[__mul24(cym + jy0, ppitch) + cxm + jx0];
-        const int t1 = patch[__mul24(cym + jy1, ppitch) + cxm + jx1];
-        val |= (t0 < t1 ? 1u : 0u) << k;
+        for (int kk = RB_UNROLL - 1; kk >= 0; kk--) {  // test 0 is shifted in last: bit 0
+            const float4 pt = pat[(k0 + kk) * DG + gl];  // (x0, y0, x1, y1) of test 16 gl + k
+            const int jx0 = __float_as_int((pt.x * a - pt.y * b) + 12582912.f), jy0 = __float_as_int((pt.x * b + pt.y * a) + 12582912.f);
+            const int jx1 = __float_as_int((pt.z * a - pt.w * b) + 12582912.f), jy1 = __float_as_int((pt.z * b + pt.w * a) + 12582912.f);
+            const uint32_t a0 = (uint32_t)__mul24(jy0, ppitch) + (base + (uint32_t)jx0), a1 = (uint32_t)__mul24(jy1, ppitch) + (base + (uint32_t)jx1);
+            const int t0 = *(lds_cu8*)(uintptr_t)a0, t1 = *(lds_cu8*)(uintptr_t)a1;
+            val = __builtin_amdgcn_alignbit(val, (uint32_t)(t0 - t1), 31);  // (val << 1) | (t0 < t1)
+        }
     }
     return (uint16_t)val;
 }
@@ -1481,11 +1489,14 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
                                                           const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
                                                           uint8_t* __restrict__ desc, int cap, int* __restrict__ counts, int* flags,
                                                           const uint32_t* __restrict__ icw) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DT_RAW_ROWS * DT_RAW_P];
-    __shared__ __attribute__((aligned(16))) uint8_t s_blr[HAS_DESC ? DT_BLR_ROWS * DT_BLR_P : 16];
+    // ONE tile buffer: the raw tile (intensity centroid, phase A) is replaced by the blurred tile (rBRIEF, phase C) once phase A is
+    // done; the blurred tile's loads are in flight since the prologue and wait in registers (18 per thread)
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[HAS_DESC ? DT_BLR_ROWS * DT_BLR_P : DT_RAW_ROWS * DT_RAW_P];
+    __shared__ __attribute__((aligned(16))) float4 s_pat[HAS_DESC ? 256 : 1];  // rBRIEF pattern as floats, [test k of a lane][lane]
     __shared__ uint32_t s_list[DT_LIST];  // index in the chunk | dx << 9 | dy << 17
     __shared__ float2 s_ab[DT_LIST];      // (-, response) -> (angle, -) -> (cos, sin)
     __shared__ int s_n;
+    static_assert(DT_BLR_ROWS * DT_BLR_P >= DT_RAW_ROWS * DT_RAW_P, "the blurred tile is the larger one");
     int frame = blockIdx.y, tile = blockIdx.x;
     xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, tile);  // XCD affinity (speed only)
     const uint32_t te = tile_tab[tile];
@@ -1514,7 +1525,6 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
     }
     nL = min(nL, max(cap - base, 0));  // rows past cap are not produced
     if (nL == 0) return;               // block-uniform
-    if (tid == 0) s_n = 0;
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     const uint8_t* bl = blur + (size_t)frame * P.blur_stride + P.lv[L].boff;
     const bool al_raw = (lpitch & 7) == 0 && (((size_t)img) & 7) == 0;
@@ -1523,7 +1533,7 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
     const int xb_al = al_blr ? (x0 - 19) & ~7 : x0 - 19;
     const FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + P.lv[L].fin_off;
     // ---- everything this workgroup reads from global memory, in flight together: the first chunk of the level's list, both tiles
-    //      (empty tiles are rare: they are loaded unconditionally), the lane's centroid weights and pattern rows
+    //      (empty tiles are rare: they are loaded unconditionally), the lane's centroid weights, the pattern
     FinalKp fk[DT_CHUNK / DT_NT];
 #pragma unroll
     for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(tid + u * DT_NT, nL - 1)];
@@ -1531,38 +1541,30 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
     if (al_raw) tile_issue<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(img, lpitch, lh, y0 - 15, xr_al, tid, vr);
     if (HAS_DESC && al_blr) tile_issue<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(bl, lbpitch, lh, y0 - 19, xb_al, tid, vb);
     // the two disc rows of this lane: rows gl and 30 - gl of the 31 (lane 15: row 15 once) have the same half-width, hence the same
-    // weight bytes (u + 16 inside the disc) and mask bytes (1 inside): 16 registers, fetched once per workgroup (the per-keypoint
-    // kernel re-read 32 dwords from LDS for every keypoint).  The lane's 16 pattern rows likewise: 16 registers.
-    uint32_t wt[8], mk[8], pat[16];
+    // weight bytes (u + 16 inside the disc) and mask bytes (1 inside): 16 registers, fetched once per workgroup
+    uint32_t wt[8], mk[8];
     {
         const uint4* w = (const uint4*)(icw + gl * 16);
         const uint4 w0 = w[0], w1 = w[1], k0 = w[2], k1 = w[3];
         wt[0] = w0.x; wt[1] = w0.y; wt[2] = w0.z; wt[3] = w0.w; wt[4] = w1.x; wt[5] = w1.y; wt[6] = w1.z; wt[7] = w1.w;
         mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
-        if (HAS_DESC) {
-            const uint4* pp = (const uint4*)(c_pattern + gl * 64);
-#pragma unroll
-            for (int q = 0; q < 4; q++) { const uint4 v = pp[q]; pat[4 * q] = v.x; pat[4 * q + 1] = v.y; pat[4 * q + 2] = v.z; pat[4 * q + 3] = v.w; }
+    }
+    if (HAS_DESC && tid < 256 && DT_NT >= 256) {  // thread t = lane l, test k of the lane: pattern row 16 l + k -> s_pat[k][l]
+        const int l = tid & 15, k = tid >> 4;
+        const int8_t* pt = &c_pattern[(l * 16 + k) * 4];
+        s_pat[k * DG + l] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
+    } else if (HAS_DESC && DT_NT < 256) {
+        for (int i = tid; i < 256; i += DT_NT) {
+            const int l = i & 15, k = i >> 4;
+            const int8_t* pt = &c_pattern[(l * 16 + k) * 4];
+            s_pat[k * DG + l] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
         }
     }
     const int row_b_w = gl == 15 ? 0 : 1;  // lane 15's second row is row 15 again: counted once
-    if (al_raw) tile_store<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(s_raw, tid, vr);
-    else tile_load_bytes(img, lpitch, lw, lh, y0 - 15, DT_RAW_ROWS, xr_al, DT_RAW_P, s_raw, tid);
-    if (HAS_DESC) {
-        if (al_blr) tile_store<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(s_blr, tid, vb);
-        else tile_load_bytes(bl, lbpitch, lw, lh, y0 - 19, DT_BLR_ROWS, xb_al, DT_BLR_P, s_blr, tid);
-    }
-    for (int c0 = 0; c0 < nL; c0 += DT_CHUNK) {  // block-uniform trip count (one trip unless a level keeps more than 512 keypoints)
-        if (c0 > 0) {
-#pragma unroll
-            for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(c0 + tid + u * DT_NT, nL - 1)];
-        }
-      // one pass over the chunk's records; a tile that holds more than DT_LIST of them (sub = -1 -> 0) is redone as DT_CHUNK / DT_NT
-      // passes over 128 records each.  Every branch below is block-uniform.
-      for (int sub = -1; sub < DT_CHUNK / DT_NT; sub++) {
-        __syncthreads();  // the previous pass has read the list (first pass: the tile stores above)
-        if (tid == 0) s_n = 0;
-        __syncthreads();
+    const uint32_t tile_lds = (uint32_t)(uintptr_t)s_tile;
+
+    // the chunk's records of this thread that fall into the tile -> list (sub >= 0: only record slot `sub` of the thread)
+    auto select = [&](int c0, int sub) {
 #pragma unroll
         for (int u = 0; u < DT_CHUNK / DT_NT; u++) {
             const int i = c0 + tid + u * DT_NT;
@@ -1575,10 +1577,9 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
                 }
             }
         }
-        __syncthreads();
-        const int n = s_n;
-        if (sub < 0 && n > DT_LIST) continue;     // too many for one pass: the sub-passes follow
-        // phase A, 16 lanes per keypoint: intensity-centroid angle, keypoint record; the angle goes into the list
+    };
+    // phase A, 16 lanes per keypoint: intensity-centroid angle out of the RAW tile, keypoint record; the angle goes into the list
+    auto phase_a = [&](int c0, int n) {
         for (int j = grp; j < n; j += DT_NT / DG) {  // uniform within a 16-lane group; no barriers inside
             const uint32_t e = s_list[j];
             const int i = c0 + (int)(e & 0x1FF), dx = (int)((e >> 9) & 255), dy = (int)(e >> 17);
@@ -1591,7 +1592,7 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 const int row_i = rr == 0 ? gl : 30 - gl;
-                const uint32_t* rowp = (const uint32_t*)(s_raw + (dy + row_i) * DT_RAW_P + (col & ~3));
+                const uint32_t* rowp = (const uint32_t*)(s_tile + (dy + row_i) * DT_RAW_P + (col & ~3));
                 uint32_t pxw[9];
 #pragma unroll
                 for (int c4 = 0; c4 < 9; c4++) pxw[c4] = rowp[c4];
@@ -1620,35 +1621,77 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
                 s_ab[j].x = angle;
             }
         }
+    };
+    // phase B, ONE lane per keypoint: (float)cos / (float)sin of the angle through f64 as cv2 computes them - once per keypoint instead
+    // of once per lane of its group (the f64 sincos is the longest straight-line piece of the kernel)
+    auto phase_b = [&](int n) {
+        for (int j = tid; j < n; j += DT_NT) {
+            float angle = s_ab[j].x;
+            angle *= (float)(3.14159265358979323846 / 180.f);
+            double sd, cd;
+            sincos((double)angle, &sd, &cd);
+            s_ab[j] = make_float2((float)cd, (float)sd);
+        }
+    };
+    // phase C, 16 lanes per keypoint: the 256 rotated tests, 16 per lane, out of the BLURRED tile
+    auto phase_c = [&](int c0, int n) {
+        for (int j = grp; j < n; j += DT_NT / DG) {
+            const uint32_t ex = s_list[j];
+            const int i = c0 + (int)(ex & 0x1FF), dx = (int)((ex >> 9) & 255), dy = (int)(ex >> 17);
+            const int k = base + i;
+            const float px = (float)(x0 + dx) * lscale, py = (float)(y0 + dy) * lscale, inv = 1.f / lscale;
+            const int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
+            const float2 ab = s_ab[j];
+            int glo = gl;
+            asm volatile("" : "+v"(glo));  // opaque per keypoint: the 16 pattern reads stay in the loop (hoisted, they pin 64 registers)
+            *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) =
+                rbrief_u16_lds(tile_lds + (uint32_t)((cy - (y0 - 19)) * DT_BLR_P + (cx - xb_al)), DT_BLR_P, ab.x, ab.y, s_pat, glo);
+        }
+    };
+
+    // ---- the common case in one pass: raw tile -> LDS, list, phase A, blurred tile over the raw one, phases B and C
+    if (tid == 0) s_n = 0;
+    if (al_raw) tile_store<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(s_tile, tid, vr);
+    else tile_load_bytes(img, lpitch, lw, lh, y0 - 15, DT_RAW_ROWS, xr_al, DT_RAW_P, s_tile, tid);
+    __syncthreads();
+    select(0, -1);
+    __syncthreads();
+    const int n0 = s_n;
+    if (nL <= DT_CHUNK && n0 <= DT_LIST) {  // block-uniform
+        phase_a(0, n0);
         if (HAS_DESC) {
+            __syncthreads();  // phase A is done with the raw tile
+            if (al_blr) tile_store<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(s_tile, tid, vb);
+            else tile_load_bytes(bl, lbpitch, lw, lh, y0 - 19, DT_BLR_ROWS, xb_al, DT_BLR_P, s_tile, tid);
+            phase_b(n0);
             __syncthreads();
-            // phase B, ONE lane per keypoint: (float)cos / (float)sin of the angle through f64 as cv2 computes them - once per keypoint
-            // instead of once per lane of its group (the f64 sincos is the longest straight-line piece of the kernel)
-            for (int j = tid; j < n; j += DT_NT) {
-                float angle = s_ab[j].x;
-                angle *= (float)(3.14159265358979323846 / 180.f);
-                double sd, cd;
-                sincos((double)angle, &sd, &cd);
-                s_ab[j] = make_float2((float)cd, (float)sd);
-            }
-            __syncthreads();
-            // phase C, 16 lanes per keypoint: the 256 rotated tests, 16 per lane, out of the blurred tile
-            for (int j = grp; j < n; j += DT_NT / DG) {
-                const uint32_t ex = s_list[j];
-                const int i = c0 + (int)(ex & 0x1FF), dx = (int)((ex >> 9) & 255), dy = (int)(ex >> 17);
-                const int k = base + i;
-                const float px = (float)(x0 + dx) * lscale, py = (float)(y0 + dy) * lscale, inv = 1.f / lscale;
-                const int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
-                const float2 ab = s_ab[j];
+            phase_c(0, n0);
+        }
+        return;
+    }
+    // ---- the rare case (a level keeps more than DT_CHUNK keypoints, or the tile holds more than DT_LIST of a chunk's): chunks of
+    //      DT_CHUNK records, each as DT_CHUNK / DT_NT passes over DT_NT records; both tiles are fetched again for every pass
+    for (int c0 = 0; c0 < nL; c0 += DT_CHUNK) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) asm volatile("" : "+v"(pat[q]));  // opaque per keypoint: the 64 int8 -> float conversions
-                                                                              // stay in the loop instead of being hoisted into 64 registers
-                *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) =
-                    rbrief_u16_reg(s_blr, DT_BLR_P, cx - xb_al, cy - (y0 - 19), ab.x, ab.y, pat);
+        for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(c0 + tid + u * DT_NT, nL - 1)];
+#pragma unroll 1
+        for (int sub = 0; sub < DT_CHUNK / DT_NT; sub++) {
+            __syncthreads();  // the previous pass is done with the list and the tile
+            if (tid == 0) s_n = 0;
+            tile_load_bytes(img, lpitch, lw, lh, y0 - 15, DT_RAW_ROWS, xr_al, DT_RAW_P, s_tile, tid);
+            __syncthreads();
+            select(c0, sub);
+            __syncthreads();
+            const int n = s_n;  // <= DT_NT <= DT_LIST
+            phase_a(c0, n);
+            if (HAS_DESC) {
+                __syncthreads();
+                tile_load_bytes(bl, lbpitch, lw, lh, y0 - 19, DT_BLR_ROWS, xb_al, DT_BLR_P, s_tile, tid);
+                phase_b(n);
+                __syncthreads();
+                phase_c(c0, n);
             }
         }
-        if (sub < 0) break;  // the whole chunk went through in one pass
-      }
     }
 }
 
