@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--sync-steps", type=int, default=0, help="1: the host waits for every step before it enqueues the next one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the extra timing of the opt-in matrix-core matcher")
-    ap.add_argument("--cpu-frames", type=int, default=64, help="frames of the batch the CPU baseline processes (bounded sample)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the batch the CPU baseline processes (bounded sample)")
     ap.add_argument("--frames-cache", default="", help="file the generated frames of this rank are kept in (.npy; created when missing): "
                                                        "profiles/collect.sh generates once and profiles only the pipeline")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other scene, next rows, H2D-inclusive, single-frame)")
