@@ -400,8 +400,10 @@ def _batch_io(torch, V, dev, frames, nb, cap, n_hyp, pair_base=0, want_mask=Fals
     return io, b, K
 
 
-def test_batched_grid_detector_equals_oracle_on_every_frame():
-    """mo_batch_io.detector = MO_DETECT_GRID: ORBExtractor.distribute_keypoints (reference extractor.py:85-144, the path
+@pytest.mark.parametrize("nb,w,h", [(16, 640, 480), (3, 1024, 768)])
+def test_batched_grid_detector_equals_oracle_on_every_frame(nb, w, h):
+    """(640 x 480: descriptors out of one LDS tile per grid cell; 1024 x 768: cells too large for the tile, one wavefront per keypoint)
+    mo_batch_io.detector = MO_DETECT_GRID: ORBExtractor.distribute_keypoints (reference extractor.py:85-144, the path
     Tracker.process_frame takes, tracker.py:87) for a whole batch in HBM.  Every frame of a 16-frame batch: all grid corners equal
     O.grid_good_features, the kept keypoints / their indices / descriptors equal O.compute on KeyPoint(x, y, 31) records, and the
     match + pose stages run on them (match lists equal the per-pair host call)."""
@@ -409,18 +411,19 @@ def test_batched_grid_detector_equals_oracle_on_every_frame():
     import vslam_amd as V
     from oracle import orb_oracle as O
     from tests.helpers import parallax_frames
-    nb, cap, nfeat = 16, 2048, 2000
+    cap, nfeat = 2048, 2000
     per_cell = nfeat // 64
-    frames = parallax_frames(nb, seed=37)
+    frames = parallax_frames(nb, seed=37, w=w, h=h)
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(st)
     try:
-        ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
+        ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=nb)
         ctx.set_stream(st.cuda_stream)
         prm = V.orb_params(nfeatures=nfeat)
         d_fr = torch.from_numpy(frames).to(dev)
         io, b, K = _batch_io(torch, V, dev, d_fr, nb, cap, 512)
+        io.w, io.h = w, h
         gxy = torch.zeros((nb, 64 * per_cell, 2), dtype=torch.float32, device=dev)
         gn = torch.zeros((nb, 66), dtype=torch.int32, device=dev)
         gkept = torch.full((nb, cap), -1, dtype=torch.int32, device=dev)
@@ -449,7 +452,7 @@ def test_batched_grid_detector_equals_oracle_on_every_frame():
             d = b["desc"][f, :n].cpu().numpy()
             assert np.array_equal(d, edesc), f
             descs.append(d)
-        host = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+        host = V.Context(device=0, max_w=w, max_h=h, max_batch=1)
         P = b["pose"].cpu().numpy()
         for i in range(nb - 1):
             idx, dist, ps = host.match_knn2_ratio(descs[i], descs[i + 1], 0.75)

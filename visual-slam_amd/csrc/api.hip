@@ -101,7 +101,8 @@ static int run_grid_extract(mo_ctx* c, const mo_orb_params* p, const mo_batch_io
     const size_t B = (size_t)batch;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_eig = take(B * w * h * sizeof(float)), o_xy = take(B * slots * 2 * sizeof(float)), o_n = take(B * 66 * sizeof(int));
+    const size_t o_eig = take(B * w * h * sizeof(float)), o_xy = take(B * slots * 2 * sizeof(float)), o_n = take(B * 66 * sizeof(int)),
+                 o_kb = take(B * 65 * sizeof(int32_t));
     if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off))) return rc;
     uint8_t* b = (uint8_t*)c->d_tmp;
     float* d_eig = (float*)(b + o_eig);
@@ -110,12 +111,17 @@ static int run_grid_extract(mo_ctx* c, const mo_orb_params* p, const mo_batch_io
     c->flags_cur = c->d_flags;
     mo_stage_begin(c);
     if ((rc = gftt_launch(c, io->d_gray, w, h, p->nfeatures, d_eig, d_xy, d_n, batch))) return rc;
-    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, io->d_kps, io->d_grid_kept, cap, io->d_counts, batch))) return rc;
+    int32_t* d_kb = (int32_t*)(b + o_kb);
+    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, io->d_kps, io->d_grid_kept, cap, io->d_counts, batch, d_kb))) return rc;
     mo_stage_mark(c, "grid_good_features");
     const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3;
     if ((rc = orb_launch_blur(c, io->d_gray, batch, 1, blur_margin))) return rc;  // the records all sit on octave 0
     mo_stage_mark(c, "blur");
-    if ((rc = orb_launch_describe_given(c, io->d_gray, io->d_kps, cap, io->d_desc, io->d_counts, batch, 1))) return rc;
+    // descriptors out of one blurred LDS tile per grid cell; cells too large for the tile (frames beyond ~ 720 x 480) take the
+    // one-wavefront-per-keypoint kernel that samples global memory
+    rc = orb_launch_describe_cells(c, io->d_kps, d_kb, io->d_desc, cap, batch);
+    if (rc == MO_ERR_UNSUPPORTED) rc = orb_launch_describe_given(c, io->d_gray, io->d_kps, cap, io->d_desc, io->d_counts, batch, 1);
+    if (rc) return rc;
     mo_stage_mark(c, "compute");
     return MO_OK;
 }

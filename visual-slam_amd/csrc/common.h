@@ -172,7 +172,10 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
 int orb_launch_describe_given(mo_ctx* c, const uint8_t* d_gray, const mo_keypoint* d_kps, int n, uint8_t* d_desc, const int* d_n = nullptr,
                               int batch = 1, int n_stride = 0);
 int gftt_records_launch(mo_ctx* c, const float* d_xy, int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
-                        int32_t* d_kept, int rec_stride, int32_t* d_counts_out, int batch);
+                        int32_t* d_kept, int rec_stride, int32_t* d_counts_out, int batch, int32_t* d_kbase = nullptr);
+// orb_kernels.hip: descriptors of the batched grid detector's records out of one blurred LDS tile per grid cell; returns MO_ERR_UNSUPPORTED
+// (without setting the error text) when a cell + halo does not fit the tile, and the caller takes orb_launch_describe_given
+int orb_launch_describe_cells(mo_ctx* c, const mo_keypoint* d_kps, const int32_t* d_kbase, uint8_t* d_desc, int cap, int batch);
 int orb_launch_retain_probe(mo_ctx* c, const float* d_resp, int n, int n_points, int order, int32_t* d_order,
                             int* d_nout);
 // match_kernels.hip

@@ -15,21 +15,25 @@ __device__ __forceinline__ int gf_reflect101(int p, int len) {
 }
 
 #define ME_TW 64
-#define ME_TH 16
+#define ME_TH 32
+#define ME_RPT (ME_TH / 4)  // output rows per thread: a wavefront owns ME_RPT consecutive rows of the tile, a lane one column
 
 // cornerMinEigenVal(blockSize 3, Sobel 3, BORDER_REFLECT_101): u8 tile (+2 halo) -> Dx, Dy (+1 halo) -> 3x3 box of the
-// covariance terms in f64 -> (a + c) - sqrt((a - c)^2 + b^2).  Round 3: the pixel tile goes through LDS once (one byte load per
-// tile pixel; rounds 1 - 2 read nine reflected bytes from global memory per gradient sample: 0.49 ms per 256 frames, now bound by
-// its arithmetic); same float expressions in the same order.
+// covariance terms in f64 -> (a + c) - sqrt((a - c)^2 + b^2).
+// Round 3: (1) the pixel tile goes through LDS once (rounds 1 - 2 read nine reflected bytes from global memory per gradient sample);
+// (2) the 3x3 box sums are SEPARABLE: a thread walks down its column keeping the horizontal 3-sums of the last three rows, 13.5
+// instead of 27 f64 additions (and conversions) per pixel.  The order of the f64 additions is free here: the terms are float32
+// products of gradients that are multiples of 1 / 3060 up to rounding, i.e. zero or between 2^-24 and 2^-1 in magnitude with 24-bit
+// mantissas - nine of them add up exactly in 53 bits whatever the order, so the result is the oracle's bit for bit.
 __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ gray, int w, int h, float* __restrict__ eig) {
     __shared__ uint8_t s_px[(ME_TH + 4) * (ME_TW + 4)];
     __shared__ float s_dx[(ME_TH + 2) * (ME_TW + 2)], s_dy[(ME_TH + 2) * (ME_TW + 2)];
     const int tx0 = blockIdx.x * ME_TW, ty0 = blockIdx.y * ME_TH, tid = threadIdx.x;
     gray += (size_t)blockIdx.z * w * h;  // frame of a batch (dense frames, dense maps)
     eig += (size_t)blockIdx.z * w * h;
-    // s_px[r][c] = pixel at (reflect(reflect(ty0 + r' - 1) + dr), ...) is NOT separable into one reflection of ty0 + r - 2: the Sobel
-    // window of a reflected gradient position is reflected again.  Away from the image border both agree, so interior tiles stage
-    // plain coordinates and border tiles (block-uniform test) keep the double reflection through an index table per axis.
+    // The Sobel window of a REFLECTED gradient position is reflected again, which is not one reflection of the pixel coordinate.
+    // Away from the image border both agree: interior tiles (block-uniform test) stage plain coordinates through LDS, border tiles
+    // evaluate the double reflection directly from global memory.
     const bool interior = tx0 >= 2 && ty0 >= 2 && tx0 + ME_TW + 2 <= w && ty0 + ME_TH + 2 <= h;
     const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float f1 = (float)(1.0f * scale_d), f0 = (float)(2.0f * scale_d);
@@ -54,8 +58,6 @@ __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ g
             s_dy[i] = Cp - Cm;
         }
     } else {
-        // Dx/Dy are needed at (reflected) coordinates y-1..y+1, x-1..x+1 of the output pixel; each of those needs pixels at
-        // its own +-1 (reflected again): evaluated directly from global memory with both reflections
         for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
             int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
             int y = gf_reflect101(ty0 + r - 1, h), x = gf_reflect101(tx0 + c - 1, w);
@@ -75,23 +77,37 @@ __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ g
         }
     }
     __syncthreads();
-    const int lx = tid & 63;
-    for (int ly = tid >> 6; ly < ME_TH; ly += 4) {
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= w || y >= h) continue;
-        double sxx = 0, sxy = 0, syy = 0;
+    const int lx = tid & 63, ly0 = (tid >> 6) * ME_RPT;
+    const int x = tx0 + lx;
+    // horizontal 3-sums (f64) of the products on gradient row r of the tile, columns lx .. lx + 2
+    auto hsum = [&](int r, double& hxx, double& hxy, double& hyy) {
+        const float* dxp = s_dx + r * (ME_TW + 2) + lx;
+        const float* dyp = s_dy + r * (ME_TW + 2) + lx;
+        hxx = 0; hxy = 0; hyy = 0;
 #pragma unroll
-        for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) {
+            const float a = dxp[i], b = dyp[i];
+            const float xx = a * a, xy = a * b, yy = b * b;
+            hxx += (double)xx; hxy += (double)xy; hyy += (double)yy;
+        }
+    };
+    double h0x, h0y, h0z, h1x, h1y, h1z;
+    hsum(ly0, h0x, h0y, h0z);
+    hsum(ly0 + 1, h1x, h1y, h1z);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                float a = s_dx[(ly + j) * (ME_TW + 2) + lx + i], b = s_dy[(ly + j) * (ME_TW + 2) + lx + i];
-                float xx = a * a, xy = a * b, yy = b * b;
-                sxx += (double)xx; sxy += (double)xy; syy += (double)yy;
-            }
-        float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
-        float amc = a - c;
-        float rad = amc * amc + b * b;
-        eig[(size_t)y * w + x] = (a + c) - sqrtf(rad);
+    for (int k = 0; k < ME_RPT; k++) {
+        double h2x, h2y, h2z;
+        hsum(ly0 + k + 2, h2x, h2y, h2z);
+        const int y = ty0 + ly0 + k;
+        if (x < w && y < h) {
+            const double sxx = (h0x + h1x) + h2x, sxy = (h0y + h1y) + h2y, syy = (h0z + h1z) + h2z;
+            float a = (float)sxx * 0.5f, b = (float)sxy, c = (float)syy * 0.5f;
+            float amc = a - c;
+            float rad = amc * amc + b * b;
+            eig[(size_t)y * w + x] = (a + c) - sqrtf(rad);
+        }
+        h0x = h1x; h0y = h1y; h0z = h1z;
+        h1x = h2x; h1y = h2y; h1z = h2z;
     }
 }
 
@@ -282,8 +298,10 @@ int gftt_launch(mo_ctx* c, const uint8_t* d_gray, int w, int h, int n_features, 
 // Records beyond rec_stride are dropped and bit 1 of the flag word is raised (the count still reports the need).
 __global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ xy, int* __restrict__ cell_n, int per_cell, int w,
                                                       int h, int edge, mo_keypoint* __restrict__ rec, int32_t* __restrict__ kept,
-                                                      int rec_stride, int32_t* __restrict__ counts_out, int* flags) {
+                                                      int rec_stride, int32_t* __restrict__ counts_out, int* flags,
+                                                      int32_t* __restrict__ kbase /* [frame][65] or null: records kept before cell c */) {
     __shared__ int s_base[65];
+    __shared__ int s_kcnt[64];
     __shared__ int s_wsum[4];
     __shared__ int s_run;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -292,6 +310,7 @@ __global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ 
     rec += (size_t)blockIdx.x * rec_stride;
     if (kept) kept += (size_t)blockIdx.x * rec_stride;
     int* counts2 = cell_n + 64;
+    if (tid < 64) s_kcnt[tid] = 0;
     if (tid == 0) {
         int a = 0;
         for (int cl = 0; cl < 64; cl++) { s_base[cl] = a; a += min(cell_n[cl], per_cell); }
@@ -305,8 +324,8 @@ __global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ 
         const int g = b0 + tid;
         bool keep = false;
         float x = 0.f, y = 0.f;
+        int cl = 0;
         if (g < total) {
-            int cl = 0;
             for (int step = 32; step > 0; step >>= 1)  // the cell whose list holds position g
                 if (cl + step < 64 && s_base[cl + step] <= g) cl += step;
             const int i = g - s_base[cl];
@@ -325,6 +344,7 @@ __global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ 
             kp.x = x; kp.y = y; kp.size = 31.f; kp.angle = -1.f; kp.response = 0.f; kp.octave = 0; kp.class_id = -1;
             rec[pos] = kp;
             if (kept) kept[pos] = g;
+            atomicAdd(&s_kcnt[cl], 1);
         }
         __syncthreads();
         if (tid == 0) s_run += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
@@ -334,13 +354,18 @@ __global__ __launch_bounds__(256) void k_gftt_records(const float* __restrict__ 
         counts2[0] = total; counts2[1] = s_run;
         if (counts_out) counts_out[blockIdx.x] = s_run;
         if (s_run > rec_stride) atomicOr(&flags[0], 2);
+        if (kbase) {
+            int a = 0;
+            for (int c2 = 0; c2 < 64; c2++) { kbase[(size_t)blockIdx.x * 65 + c2] = a; a += s_kcnt[c2]; }
+            kbase[(size_t)blockIdx.x * 65 + 64] = a;
+        }
     }
 }
 
 int gftt_records_launch(mo_ctx* c, const float* d_xy, int* d_cell_n, int per_cell, int w, int h, int edge, mo_keypoint* d_rec,
-                        int32_t* d_kept, int rec_stride, int32_t* d_counts_out, int batch) {
+                        int32_t* d_kept, int rec_stride, int32_t* d_counts_out, int batch, int32_t* d_kbase) {
     hipLaunchKernelGGL(k_gftt_records, dim3(batch), dim3(256), 0, c->stream, d_xy, d_cell_n, per_cell, w, h, edge, d_rec, d_kept, rec_stride,
-                       d_counts_out, c->flags_cur);
+                       d_counts_out, c->flags_cur, d_kbase);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

@@ -1778,6 +1778,82 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
     return MO_OK;
 }
 
+// ------------------------------------------------------------------ describe, grid cells (batched grid detector) ----
+// Descriptors of the records k_gftt_records keeps (octave 0, angle as recorded: -1), one workgroup per grid cell: the blurred level-0
+// tile of the cell (+ 19 px) goes through LDS once, the cell's records - a contiguous range of the frame's list, kbase[cell] ..
+// kbase[cell + 1] - are described out of it 16 lanes each, like phase B / C of k_describe_tiles (k_describe_given samples global
+// memory through one wavefront per keypoint: 0.26 ms per 256 frames of 1 140 records).
+#define DC_TILE_BYTES 13312   // (80 + 38 + 14 -> 128) x (60 + 38) at 640 x 480 = 12 544
+#define DC_MAXREC 256         // GF_MAXCORNERS: records per cell
+__global__ __launch_bounds__(256) void k_describe_cells(Plan P, const uint8_t* __restrict__ blur, const mo_keypoint* __restrict__ kps,
+                                                        const int32_t* __restrict__ kbase, uint8_t* __restrict__ desc, int cap, int cw,
+                                                        int ch, int tpitch) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[DC_TILE_BYTES];
+    __shared__ __attribute__((aligned(16))) float4 s_pat[256];
+    __shared__ float2 s_ab[DC_MAXREC];
+    __shared__ uint32_t s_ctr[DC_MAXREC];  // LDS address of the record's centre sample
+    const int cell = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x, grp = tid / DG, gl = tid % DG;
+    const int i0 = kbase[(size_t)frame * 65 + cell], n = min(kbase[(size_t)frame * 65 + cell + 1] - i0, DC_MAXREC);
+    if (n <= 0) return;  // block-uniform
+    const int x0 = (cell & 7) * cw, y0 = (cell >> 3) * ch;
+    const LevelInfo lv = P.lv[0];
+    const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
+    const int xb_al = (x0 - 19) & ~7, rows = ch + 38, nq = tpitch >> 3, last_q = (lv.bpitch >> 3) - 1;
+    {   // tile: every 8-byte piece in flight before the first store (rows clamped into the level, pieces into the row pitch)
+        constexpr int U = 8;
+        const int total = rows * nq;
+        const uint32_t inv = 0xFFFFFFFFu / (uint32_t)nq + 1u;
+        for (int t0 = tid; t0 < total; t0 += 256 * U) {
+            uint2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = min(t0 + u * 256, total - 1), r = (int)__umulhi((uint32_t)t, inv), c = t - r * nq;
+                const int y = min(max(y0 - 19 + r, 0), lv.h - 1), q = min(max((xb_al >> 3) + c, 0), last_q);
+                v[u] = ((const uint2*)(bl + (size_t)y * lv.bpitch))[q];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int t = t0 + u * 256, r = (int)__umulhi((uint32_t)t, inv), c = t - r * nq;
+                if (t < total) *(uint2*)(s_tile + r * tpitch + 8 * c) = v[u];
+            }
+        }
+    }
+    {
+        const int l = tid & 15, k = tid >> 4;
+        const int8_t* pt = &c_pattern[(l * 16 + k) * 4];
+        s_pat[k * DG + l] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
+    }
+    const uint32_t tile_lds = (uint32_t)(uintptr_t)s_tile;
+    for (int j = tid; j < n; j += 256) {  // one lane per record: centre and (float)cos / (float)sin through f64 as cv2 computes them
+        const mo_keypoint kp = kps[(size_t)frame * cap + i0 + j];
+        const float inv = 1.f / lv.scale;
+        const int cx = __float2int_rn(kp.x * inv), cy = __float2int_rn(kp.y * inv);
+        float angle = kp.angle;
+        angle *= (float)(3.14159265358979323846 / 180.f);
+        double sd, cd;
+        sincos((double)angle, &sd, &cd);
+        s_ab[j] = make_float2((float)cd, (float)sd);
+        s_ctr[j] = tile_lds + (uint32_t)((cy - (y0 - 19)) * tpitch + (cx - xb_al));
+    }
+    __syncthreads();
+    for (int j = grp; j < n; j += 256 / DG) {
+        const float2 ab = s_ab[j];
+        int glo = gl;
+        asm volatile("" : "+v"(glo));  // (keeps the 16 pattern reads inside the loop)
+        *(uint16_t*)(desc + ((size_t)frame * cap + i0 + j) * 32 + 2 * gl) = rbrief_u16_lds(s_ctr[j], tpitch, ab.x, ab.y, s_pat, glo);
+    }
+}
+
+int orb_launch_describe_cells(mo_ctx* c, const mo_keypoint* d_kps, const int32_t* d_kbase, uint8_t* d_desc, int cap, int batch) {
+    const Plan& P = c->plan;
+    const int cw = P.w / 8, ch = P.h / 8;
+    const int tpitch = (cw + 38 + 7 + 7) & ~7;
+    if ((size_t)tpitch * (ch + 38) > DC_TILE_BYTES || P.edge_threshold < 19) return MO_ERR_UNSUPPORTED;  // (the caller falls back)
+    hipLaunchKernelGGL(k_describe_cells, dim3(64, batch), dim3(256), 0, c->stream, P, c->d_blur, d_kps, d_kbase, d_desc, cap, cw, ch, tpitch);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
 // compute() with caller keypoints: angle as supplied, level = kp.octave.  blockIdx.y = frame of a batch (the batched grid detector):
 // records kps + frame * cap, descriptors desc + frame * cap * 32, record count n_dev[frame * n_stride] (n_dev null: n).
 __global__ __launch_bounds__(256) void k_describe_given(Plan P, const uint8_t* __restrict__ gray,
