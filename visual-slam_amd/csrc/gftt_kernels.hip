@@ -38,9 +38,17 @@ __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ g
     const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float f1 = (float)(1.0f * scale_d), f0 = (float)(2.0f * scale_d);
     if (interior) {
-        for (int i = tid; i < (ME_TH + 4) * (ME_TW + 4); i += 256) {
-            const int r = i / (ME_TW + 4), c = i - r * (ME_TW + 4);
-            s_px[i] = gray[(size_t)(ty0 + r - 2) * w + tx0 + c - 2];
+        {   // all byte loads of a thread in flight before the first store (a plain loop makes one global round trip per byte)
+            constexpr int NPX = (ME_TH + 4) * (ME_TW + 4), NLD = (NPX + 255) / 256;
+            uint8_t v[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; u++) {
+                const int i = min(tid + u * 256, NPX - 1), r = i / (ME_TW + 4), c = i - r * (ME_TW + 4);
+                v[u] = gray[(size_t)(ty0 + r - 2) * w + tx0 + c - 2];
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; u++)
+                if (tid + u * 256 < NPX) s_px[tid + u * 256] = v[u];
         }
         __syncthreads();
         for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
@@ -111,19 +119,21 @@ __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ g
     }
 }
 
-#define GF_CAP 4096       // local maxima per cell held in LDS
+#define GF_CAP 2048       // local maxima per cell that can be sorted (bit 2 of the flag word beyond)
 #define GF_MAXCORNERS 256
 
 #define GF_TILE_MAX 5248  // floats of the cell + 1-px ring held in LDS ((80 + 2) x (60 + 2) = 5084 at 640 x 480); larger cells read the map from global memory
-#define GF_TILE_KEYS (GF_CAP - GF_TILE_MAX / 2)  // the tile lives in the upper part of the key array: keys [0, 1472) may be filled while it is in use
+#define GF_TILE_KEYS 1024  // keys that may be filled while the tile is in use (typical: 50 - 120 local maxima per cell); the tile lies behind
+                          // them in the same array and becomes key space when a cell has more (29 KB in all: 5 workgroups per CU)
 
 // one workgroup per grid cell (blockIdx.y = frame of a batch)
 __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig, int w, int h, int cols, int cw, int ch,
                                                    int max_corners, double quality, double min_dist, float* __restrict__ out_xy,
                                                    int* __restrict__ out_n, int* flags) {
-    __shared__ unsigned long long s_key[GF_CAP];
+    __shared__ unsigned long long s_key[GF_TILE_KEYS + GF_TILE_MAX / 2];
+    static_assert(GF_TILE_KEYS + GF_TILE_MAX / 2 >= GF_CAP, "the key array with the tile's space holds GF_CAP keys");
     float* const s_tile = (float*)(s_key + GF_TILE_KEYS);  // dead once the candidates are listed; a cell with more than GF_TILE_KEYS
-                                                           // local maxima (typical: 300) lists them again from global memory
+                                                           // local maxima lists them again from global memory
     __shared__ float s_red[4];
     __shared__ int s_n;
     __shared__ float s_ax[GF_MAXCORNERS], s_ay[GF_MAXCORNERS];
@@ -140,12 +150,22 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     // read the map from global memory up to ten times per pixel (maximum, threshold, 3x3 dilation)
     const int tw = cw + 2, th = ch + 2;
     const bool in_lds = tw * th <= GF_TILE_MAX;  // block-uniform
-    if (in_lds)
-        for (int i = tid; i < tw * th; i += 256) {
-            const int r = i / tw, c = i - r * tw;
-            const int yy = min(max(y0 - 1 + r, 0), h - 1), xx = min(max(x0 - 1 + c, 0), w - 1);
-            s_tile[i] = eig[(size_t)yy * w + xx];
+    if (in_lds) {  // GF_LD loads per thread in flight before the first store (a plain loop makes one global round trip per value)
+        constexpr int GF_LD = 8;
+        const uint32_t inv_tw = 0xFFFFFFFFu / (uint32_t)tw + 1u;
+        for (int i0 = tid; i0 < tw * th; i0 += 256 * GF_LD) {
+            float v[GF_LD];
+#pragma unroll
+            for (int u = 0; u < GF_LD; u++) {
+                const int i = min(i0 + u * 256, tw * th - 1), r = (int)__umulhi((uint32_t)i, inv_tw), c = i - r * tw;
+                const int yy = min(max(y0 - 1 + r, 0), h - 1), xx = min(max(x0 - 1 + c, 0), w - 1);
+                v[u] = eig[(size_t)yy * w + xx];
+            }
+#pragma unroll
+            for (int u = 0; u < GF_LD; u++)
+                if (i0 + u * 256 < tw * th) s_tile[i0 + u * 256] = v[u];
         }
+    }
     if (tid == 0) s_n = 0;
     __syncthreads();
     // 1. cell maximum (minMaxLoc with the cell mask)
