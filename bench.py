@@ -205,7 +205,10 @@ def main():
     torch.cuda.set_stream(main_s)
     # N > 1 under RCCL: the gather goes through the library's own entry point (mo_comm_init / mo_gather_map_points); if that
     # communicator cannot be set up on some rank, every rank falls back to torch.distributed's gather (agreed by an all-reduce)
-    rccl = {"on": world > 1 and args.backend == "nccl"}
+    # BENCH_FORCE_GATHER=1 (rehearsal on a one-GPU box): the RCCL gather path - communicator, side stream, alternating buffers, the
+    # checks on rank 0 - runs on a world of one (a self send / recv); everything except torch.distributed's part of it
+    force_gather = world == 1 and os.environ.get("BENCH_FORCE_GATHER") == "1"
+    rccl = {"on": (world > 1 and args.backend == "nccl") or force_gather}
 
     class Pipeline:
         """This rank's context, input frames and output buffers for nb frames (n_pairs = nb - 1 consecutive pairs)."""
@@ -221,7 +224,7 @@ def main():
             self.counts = z(n)
             self.midx = z(n - 1, CAP, 2); self.mdist = z(n - 1, CAP, 2); self.mpass = z(n - 1, CAP, dt=torch.uint8)
             self.pose = z(n - 1, 12, dt=torch.float64)
-            self.pts = [z(rows, CAP, 3, dt=torch.float32) for _ in range(2 if world > 1 else 1)]  # N > 1: steps alternate (see Gather)
+            self.pts = [z(rows, CAP, 3, dt=torch.float32) for _ in range(2 if world > 1 or force_gather else 1)]  # N > 1: steps alternate (see Gather)
             self.npts = z(rows)
             io = V.BatchIO()
             io.d_gray = frames.data_ptr(); io.w = W; io.h = H; io.batch = n; io.cap = CAP
@@ -318,7 +321,8 @@ def main():
                     ids[0] = V.Context.comm_unique_id()
                 except Exception as e:
                     print("mo_comm_unique_id failed (%s): falling back to torch.distributed.gather" % e, file=sys.stderr)
-            dist.broadcast_object_list(ids, src=0)
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
             ok = 0
             if ids[0] is not None:
                 try:
@@ -326,10 +330,12 @@ def main():
                     ok = 1
                 except Exception as e:
                     print("rank %d: mo_comm_init failed (%s)" % (rank, e), file=sys.stderr)
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            rccl["on"] = bool(int(flag.item()))
-        ga = Gather(pl, B, n_pairs, pairs_all) if world > 1 else None
+            if world > 1:
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            rccl["on"] = bool(ok)
+        ga = Gather(pl, B, n_pairs, pairs_all) if world > 1 or rccl["on"] else None
 
         def step():
             if ga:

@@ -132,3 +132,22 @@ def test_bench_launch_contract_two_ranks_gloo():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * 16 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 0.01  # whole-job frames / time
+
+
+def test_bench_rccl_gather_path_on_a_world_of_one():
+    """bench.py with BENCH_FORCE_GATHER=1: the N > 1 gather path of the benchmark - mo_comm_unique_id / mo_comm_init, mo_gather_map_points
+    on a side stream beside the next step, two alternating map-point buffers, the drained gathers inside the timed region and rank 0's
+    checks of the gathered slab - on a world of one (RCCL refuses two ranks on one device; the multi-GPU box is the driver's)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_GATHER="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--batch", "32", "--prewarm-ms", "20",
+                          "--no-cpu-baseline", "--no-optin", "--no-extras"], capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    if d["config"]["rccl_ranks"] == 0:
+        pytest.skip("RCCL could not be loaded on this box: " + out.stderr[-300:])
+    assert d["config"]["rccl_ranks"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
+    assert "mo_gather_map_points" in d["config"]["parallelism"]
