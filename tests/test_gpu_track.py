@@ -113,3 +113,63 @@ def test_track_mode_of_the_batched_call_vs_oracle():
                                             feats[1][1], K, frames[0].shape, ratio_threshold=0.75, threshold_percent=0.02)
     assert ok and T.shape == (4, 4) and len(inl) > 50
     ctx.close(); host.close()
+
+
+@pytest.mark.parametrize("detector", ["orb", "grid"])
+@pytest.mark.parametrize("mode", ["init", "track", "keyframe"])
+def test_every_mode_runs_on_every_detector(detector, mode):
+    """mo_dev_frontend_batch: the three pose modes (MapInitializer / Tracker / LocalMapper) on both extraction paths (FAST pyramid /
+    grid Shi-Tomasi) of one 12-frame batch: no capacity flag, finite poses (or F) for nearly every pair, consistent counts."""
+    import ctypes as C
+    import torch
+    import vslam_amd as V
+    from tests.helpers import parallax_frames
+    from tests.test_gpu_dropin import _batch_io
+    nb, cap = 12, 2048
+    # fresh sensor noise per frame: without it the whole-pixel pans give IDENTICAL level-0 descriptors in consecutive frames, the
+    # median match distance is 0 and the tracker's 2 x median filter (matcher.py:144-169) keeps nothing - in the reference as here
+    rng = np.random.Generator(np.random.PCG64(5))
+    frames = np.clip(parallax_frames(nb, seed=53).astype(np.float32) + rng.normal(0, 2.0, (nb, 480, 640)), 0, 255).round().astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(st)
+    try:
+        ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=nb)
+        ctx.set_stream(st.cuda_stream)
+        prm = V.orb_params(nfeatures=2000)
+        io, b, K = _batch_io(torch, V, dev, torch.from_numpy(frames).to(dev), nb, cap, 512, want_mask=True)
+        io.detector = V.DETECT_GRID if detector == "grid" else V.DETECT_ORB
+        keep = []
+        if mode == "track":
+            sel = torch.zeros((nb - 1, cap, 2), dtype=torch.int32, device=dev); seln = torch.zeros(nb - 1, dtype=torch.int32, device=dev)
+            io.mode = V.MODE_TRACK; io.disp_frac = 0.02; io.thr_px = 1.0; io.d_sel_idx = sel.data_ptr(); io.d_sel_n = seln.data_ptr()
+            keep += [sel, seln]
+        elif mode == "keyframe":
+            pairs = [(0, 4), (4, 8), (8, 11)]
+            q = torch.tensor([p[0] for p in pairs], dtype=torch.int32, device=dev); t = torch.tensor([p[1] for p in pairs], dtype=torch.int32, device=dev)
+            P = np.zeros((len(pairs), 2, 3, 4)); P[:, :, :, :3] = K
+            for j, (a, c2) in enumerate(pairs):
+                P[j, 0, :, 3] = K @ np.array([-0.05 * a, 0, 0]); P[j, 1, :, 3] = K @ np.array([-0.05 * c2, 0, 0])
+            dP1 = torch.from_numpy(np.ascontiguousarray(P[:, 0].reshape(-1, 12))).to(dev); dP2 = torch.from_numpy(np.ascontiguousarray(P[:, 1].reshape(-1, 12))).to(dev)
+            dF = torch.zeros((len(pairs), 9), dtype=torch.float64, device=dev)
+            io.mode = V.MODE_KEYFRAME; io.ratio = 0.8; io.n_kf_pairs = len(pairs); io.d_kf_query = q.data_ptr(); io.d_kf_train = t.data_ptr()
+            io.d_kf_P1 = dP1.data_ptr(); io.d_kf_P2 = dP2.data_ptr(); io.d_kf_F = dF.data_ptr()
+            keep += [q, t, dP1, dP2, dF]
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        st.synchronize()
+        assert ctx.dev_status() == 0
+        cn = b["counts"].cpu().numpy()
+        assert (cn > 300).all() and (cn <= 2000).all()
+        if mode == "keyframe":
+            F = keep[-1].cpu().numpy()
+            assert np.isfinite(F).all() and (b["npts"][:3].cpu().numpy() > 50).all()
+            X = b["pts"][:3].cpu().numpy(); m = b["pmask"][:3].cpu().numpy().astype(bool)
+            assert np.isnan(X[~m]).all() and not np.isnan(X[m]).any()
+        else:
+            P = b["pose"].cpu().numpy()
+            assert np.isfinite(P).all(axis=1).sum() >= nb - 2
+            if mode == "track":
+                assert (keep[1].cpu().numpy() > 30).sum() >= nb - 2
+        ctx.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(dev))
