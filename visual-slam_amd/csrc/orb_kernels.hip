@@ -963,11 +963,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
                                                         const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
                                                         uint64_t* __restrict__ scratch, size_t scratch_stride,
                                                         FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags,
-                                                        int level0, int buf_bytes) {
+                                                        int level0, int buf_bytes, int* __restrict__ desc_todo) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less)
     __shared__ int s_pref[SEL_MAXSTRIPS + 1];
     __shared__ replay::WgScratch s_ws;
     const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;  // dispatch order: all frames of the finest level first
+    if (desc_todo && frame == 0 && blockIdx.y == 0 && tid == 0) desc_todo[0] = 0;  // k_describe_tiles' list of left-over tiles (this call's)
     const LevelInfo lv = P.lv[L];
     int* fin_cnt_out = &fin_cnt[(size_t)frame * MO_MAX_LEVELS + L];
     if (lv.nstrips == 0) {
@@ -1056,7 +1057,7 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo,
     // 0.23 - 0.25 ms against 0.20 ms; selecting the finest level on the auxiliary stream beside FAST of the others: no gain
     // (the coarse levels alone take 0.19 ms: the kernel is bound by the sum of the replays, not by the finest level).
     hipLaunchKernelGGL(k_select, dim3(batch, level_hi - level_lo), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
-                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES);
+                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES, c->d_dtodo);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
@@ -1482,13 +1483,17 @@ __device__ __forceinline__ void tile_load_bytes(const uint8_t* img, int pitch, i
     }
 }
 
-template <bool HAS_DESC>
-__global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
-                                                          const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
-                                                          const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
-                                                          const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
-                                                          uint8_t* __restrict__ desc, int cap, int* __restrict__ counts, int* flags,
-                                                          const uint32_t* __restrict__ icw) {
+// RARE = false: the common case in ONE pass (the level keeps <= DT_CHUNK keypoints and the tile <= DT_LIST of them); a tile that needs
+// more appends itself to `todo` and is redone by k_describe_tiles_rare (RARE = true: chunks of DT_CHUNK records, DT_CHUNK / DT_NT
+// passes each, both tiles fetched again for every pass).  Two kernels because the generic loop beside the one-pass form costs the
+// latter 34 registers (125 instead of 91: 4 instead of 5 wavefronts per SIMD).
+template <bool HAS_DESC, bool RARE>
+__device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile, int tiles_per_frame, const uint32_t* __restrict__ tile_tab,
+                                              const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                              const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
+                                              const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
+                                              uint8_t* __restrict__ desc, int cap, int* __restrict__ counts, int* flags,
+                                              const uint32_t* __restrict__ icw, int* __restrict__ todo) {
     // ONE tile buffer: the raw tile (intensity centroid, phase A) is replaced by the blurred tile (rBRIEF, phase C) once phase A is
     // done; the blurred tile's loads are in flight since the prologue and wait in registers (18 per thread)
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[HAS_DESC ? DT_BLR_ROWS * DT_BLR_P : DT_RAW_ROWS * DT_RAW_P];
@@ -1497,8 +1502,6 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
     __shared__ float2 s_ab[DT_LIST];      // (-, response) -> (angle, -) -> (cos, sin)
     __shared__ int s_n;
     static_assert(DT_BLR_ROWS * DT_BLR_P >= DT_RAW_ROWS * DT_RAW_P, "the blurred tile is the larger one");
-    int frame = blockIdx.y, tile = blockIdx.x;
-    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, tile);  // XCD affinity (speed only)
     const uint32_t te = tile_tab[tile];
     const int L = te & 0xFF;
     const int x0 = P.lv[L].bx0 + (int)((te >> 8) & 0xFFF) * DT_W, y0 = P.lv[L].by0 + (int)(te >> 20) * DT_H;
@@ -1519,7 +1522,7 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
             total += n;
         }
     }
-    if (tile == 0 && tid == 0) {
+    if (!RARE && tile == 0 && tid == 0) {
         counts[frame] = total;
         if (total > cap) atomicOr(&flags[0], 2);
     }
@@ -1535,11 +1538,13 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
     // ---- everything this workgroup reads from global memory, in flight together: the first chunk of the level's list, both tiles
     //      (empty tiles are rare: they are loaded unconditionally), the lane's centroid weights, the pattern
     FinalKp fk[DT_CHUNK / DT_NT];
-#pragma unroll
-    for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(tid + u * DT_NT, nL - 1)];
     uint2 vr[DT_RAW_LD], vb[DT_BLR_LD];  // (vb stays unused, and is dropped by the compiler, without descriptors)
-    if (al_raw) tile_issue<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(img, lpitch, lh, y0 - 15, xr_al, tid, vr);
-    if (HAS_DESC && al_blr) tile_issue<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(bl, lbpitch, lh, y0 - 19, xb_al, tid, vb);
+    if (!RARE) {
+#pragma unroll
+        for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(tid + u * DT_NT, nL - 1)];
+        if (al_raw) tile_issue<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(img, lpitch, lh, y0 - 15, xr_al, tid, vr);
+        if (HAS_DESC && al_blr) tile_issue<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(bl, lbpitch, lh, y0 - 19, xb_al, tid, vb);
+    }
     // the two disc rows of this lane: rows gl and 30 - gl of the 31 (lane 15: row 15 once) have the same half-width, hence the same
     // weight bytes (u + 16 inside the disc) and mask bytes (1 inside): 16 registers, fetched once per workgroup
     uint32_t wt[8], mk[8];
@@ -1649,15 +1654,19 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
         }
     };
 
-    // ---- the common case in one pass: raw tile -> LDS, list, phase A, blurred tile over the raw one, phases B and C
-    if (tid == 0) s_n = 0;
-    if (al_raw) tile_store<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(s_tile, tid, vr);
-    else tile_load_bytes(img, lpitch, lw, lh, y0 - 15, DT_RAW_ROWS, xr_al, DT_RAW_P, s_tile, tid);
-    __syncthreads();
-    select(0, -1);
-    __syncthreads();
-    const int n0 = s_n;
-    if (nL <= DT_CHUNK && n0 <= DT_LIST) {  // block-uniform
+    if (!RARE) {
+        // ---- the common case in one pass: raw tile -> LDS, list, phase A, blurred tile over the raw one, phases B and C
+        if (tid == 0) s_n = 0;
+        if (al_raw) tile_store<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(s_tile, tid, vr);
+        else tile_load_bytes(img, lpitch, lw, lh, y0 - 15, DT_RAW_ROWS, xr_al, DT_RAW_P, s_tile, tid);
+        __syncthreads();
+        select(0, -1);
+        __syncthreads();
+        const int n0 = s_n;
+        if (nL > DT_CHUNK || n0 > DT_LIST) {  // block-uniform: left to k_describe_tiles_rare
+            if (tid == 0) todo[1 + atomicAdd(&todo[0], 1)] = frame * tiles_per_frame + tile;
+            return;
+        }
         phase_a(0, n0);
         if (HAS_DESC) {
             __syncthreads();  // phase A is done with the raw tile
@@ -1669,8 +1678,7 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
         }
         return;
     }
-    // ---- the rare case (a level keeps more than DT_CHUNK keypoints, or the tile holds more than DT_LIST of a chunk's): chunks of
-    //      DT_CHUNK records, each as DT_CHUNK / DT_NT passes over DT_NT records; both tiles are fetched again for every pass
+    // ---- the rare case: chunks of DT_CHUNK records, each as DT_CHUNK / DT_NT passes over DT_NT records
     for (int c0 = 0; c0 < nL; c0 += DT_CHUNK) {
 #pragma unroll
         for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(c0 + tid + u * DT_NT, nL - 1)];
@@ -1692,6 +1700,36 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t
                 phase_c(c0, n);
             }
         }
+    }
+    __syncthreads();  // (the next todo entry of this workgroup reuses the tile and the list)
+}
+
+template <bool HAS_DESC>
+__global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
+                                                          const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                                          const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
+                                                          const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
+                                                          uint8_t* __restrict__ desc, int cap, int* __restrict__ counts, int* flags,
+                                                          const uint32_t* __restrict__ icw, int* __restrict__ todo) {
+    int frame = blockIdx.y, tile = blockIdx.x;
+    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, tile);  // XCD affinity (speed only)
+    describe_tile<HAS_DESC, false>(P, frame, tile, (int)gridDim.x, tile_tab, gray, pyr, blur, fin_all, fin_cnt, kps, desc, cap, counts, flags, icw, todo);
+}
+
+// the tiles the one-pass kernel left over (todo[0] of them, usually none: the workgroups then leave at once); todo[0] is cleared by the
+// next call's k_select
+template <bool HAS_DESC>
+__global__ __launch_bounds__(DT_NT) void k_describe_tiles_rare(Plan P, const uint32_t* __restrict__ tile_tab, int tiles_per_frame,
+                                                               const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+                                                               const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
+                                                               const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
+                                                               uint8_t* __restrict__ desc, int cap, int* __restrict__ counts, int* flags,
+                                                               const uint32_t* __restrict__ icw, int* __restrict__ todo) {
+    const int n = todo[0];
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {  // block-uniform
+        const int ft = todo[1 + e];
+        describe_tile<HAS_DESC, true>(P, ft / tiles_per_frame, ft % tiles_per_frame, tiles_per_frame, tile_tab, gray, pyr, blur, fin_all, fin_cnt, kps,
+                                      desc, cap, counts, flags, icw, todo);
     }
 }
 
@@ -1768,12 +1806,28 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
     }
     const dim3 grid(c->n_dtiles, batch);
     const uint32_t inv_per = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
-    if (d_desc)
+    // todo list of the tiles the one-pass kernel leaves to k_describe_tiles_rare: [0] count (cleared by k_select of the same call), then
+    // frame * tiles + tile entries; sized for every tile of the largest batch
+    const size_t todo_need = (1 + (size_t)c->n_dtiles * c->batch_alloc) * sizeof(int);
+    if (c->dtodo_bytes < todo_need) {
+        if (c->d_dtodo) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_dtodo)); c->d_dtodo = nullptr; c->dtodo_bytes = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_dtodo, todo_need));
+        HIPCHK(c, hipMemsetAsync(c->d_dtodo, 0, sizeof(int), c->stream));
+        c->dtodo_bytes = todo_need;
+    }
+    const uint32_t* icw = c->d_dtile_tab + c->dtile_icw_off;
+    const dim3 rare_grid(std::min(c->n_dtiles * batch, 256));
+    if (d_desc) {
         hipLaunchKernelGGL(k_describe_tiles<true>, grid, dim3(DT_NT), 0, c->stream, P, c->d_dtile_tab, inv_per, d_gray, c->d_pyr, c->d_blur,
-                           c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_dtile_tab + c->dtile_icw_off);
-    else
+                           c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, icw, c->d_dtodo);
+        hipLaunchKernelGGL(k_describe_tiles_rare<true>, rare_grid, dim3(DT_NT), 0, c->stream, P, c->d_dtile_tab, c->n_dtiles, d_gray, c->d_pyr,
+                           c->d_blur, c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, icw, c->d_dtodo);
+    } else {
         hipLaunchKernelGGL(k_describe_tiles<false>, grid, dim3(DT_NT), 0, c->stream, P, c->d_dtile_tab, inv_per, d_gray, c->d_pyr, c->d_blur,
-                           c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_dtile_tab + c->dtile_icw_off);
+                           c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, icw, c->d_dtodo);
+        hipLaunchKernelGGL(k_describe_tiles_rare<false>, rare_grid, dim3(DT_NT), 0, c->stream, P, c->d_dtile_tab, c->n_dtiles, d_gray, c->d_pyr,
+                           c->d_blur, c->d_fin, c->d_fin_cnt, d_kps, d_desc, cap, d_counts, c->flags_cur, icw, c->d_dtodo);
+    }
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
