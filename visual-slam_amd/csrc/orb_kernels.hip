@@ -1448,6 +1448,11 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
 #ifndef DT_NT
 #define DT_NT 256                    // 16 keypoint groups of 16 lanes
 #endif
+#ifdef DT_WAVES
+#define DT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(DT_WAVES, 8)))
+#else
+#define DT_WAVES_ATTR
+#endif
 #define DT_CHUNK 512                 // entries of the level's list examined per pass (a 2000-feature level 0 holds 434)
 #define DT_LIST (DT_NT > 160 ? DT_NT : 160)  // keypoints of the tile described per pass (typical: 6 on level 0, 60 on level 7; a sub-pass examines DT_NT records); 7 workgroups per CU
 #define DT_RAW_LD ((DT_RAW_ROWS * (DT_RAW_P / 8) + DT_NT - 1) / DT_NT)   // 8-byte loads per thread: 10
@@ -1535,15 +1540,14 @@ __device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile
     const int xr_al = al_raw ? (x0 - 15) & ~7 : x0 - 15, lead_r = (x0 - 15) - xr_al;   // raw tile column 0 = level column xr_al
     const int xb_al = al_blr ? (x0 - 19) & ~7 : x0 - 19;
     const FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + P.lv[L].fin_off;
-    // ---- everything this workgroup reads from global memory, in flight together: the first chunk of the level's list, both tiles
-    //      (empty tiles are rare: they are loaded unconditionally), the lane's centroid weights, the pattern
+    // ---- the prologue's global reads, in flight together: the first chunk of the level's list, the raw tile (empty tiles are rare: it is
+    //      loaded unconditionally), the lane's centroid weights, the pattern
     FinalKp fk[DT_CHUNK / DT_NT];
     uint2 vr[DT_RAW_LD], vb[DT_BLR_LD];  // (vb stays unused, and is dropped by the compiler, without descriptors)
     if (!RARE) {
 #pragma unroll
         for (int u = 0; u < DT_CHUNK / DT_NT; u++) fk[u] = fin[min(tid + u * DT_NT, nL - 1)];
         if (al_raw) tile_issue<DT_RAW_ROWS, DT_RAW_P / 8, DT_RAW_LD>(img, lpitch, lh, y0 - 15, xr_al, tid, vr);
-        if (HAS_DESC && al_blr) tile_issue<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(bl, lbpitch, lh, y0 - 19, xb_al, tid, vb);
     }
     // the two disc rows of this lane: rows gl and 30 - gl of the 31 (lane 15: row 15 once) have the same half-width, hence the same
     // weight bytes (u + 16 inside the disc) and mask bytes (1 inside): 16 registers, fetched once per workgroup
@@ -1669,10 +1673,13 @@ __device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile
         }
         phase_a(0, n0);
         if (HAS_DESC) {
-            __syncthreads();  // phase A is done with the raw tile
+            // the blurred tile's loads are issued HERE, not in the prologue (held in registers through phase A they cost 18 VGPRs and the
+            // sixth wavefront per SIMD: 91 -> 73); they are in flight during the barrier and the sincos phase
+            if (al_blr) tile_issue<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(bl, lbpitch, lh, y0 - 19, xb_al, tid, vb);
+            __syncthreads();  // phase A is done with the raw tile, the angles are in the list
+            phase_b(n0);
             if (al_blr) tile_store<DT_BLR_ROWS, DT_BLR_P / 8, DT_BLR_LD>(s_tile, tid, vb);
             else tile_load_bytes(bl, lbpitch, lw, lh, y0 - 19, DT_BLR_ROWS, xb_al, DT_BLR_P, s_tile, tid);
-            phase_b(n0);
             __syncthreads();
             phase_c(0, n0);
         }
@@ -1705,7 +1712,7 @@ __device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile
 }
 
 template <bool HAS_DESC>
-__global__ __launch_bounds__(DT_NT) void k_describe_tiles(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
+__global__ __launch_bounds__(DT_NT) DT_WAVES_ATTR void k_describe_tiles(Plan P, const uint32_t* __restrict__ tile_tab, uint32_t inv_per,
                                                           const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                           const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                                           const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
