@@ -48,7 +48,7 @@ STAGE_BYTES = {
     "two_view": 32000,               # per PAIR: correspondences in (<= 2000 x 16 B)
 }
 STAGE_KERNELS = {"pyramid": ["k_resize2", "k_resize"], "fast_nms": ["k_fast"], "select_harris": ["k_select"], "blur": ["k_blur"],
-                 "angle_rbrief": ["k_describe"], "match_knn2_ratio": ["k_match_lds"],
+                 "angle_rbrief": ["k_describe_tiles", "k_describe_tiles_rare"], "match_knn2_ratio": ["k_match_lds"],
                  "two_view": ["k_tv_prep", "k_tv_hyp", "k_tv_tasks", "k_tv_score", "k_tv_finish"]}
 
 
