@@ -600,6 +600,7 @@ def main():
             #     Tracker would see per call (BASELINE config 2; extract_features(distributed=True) is Tracker's default path)
             from orbslam2.extractor import ORBExtractor
             from orbslam2.matcher import DescriptorMatcher
+            from orbslam2 import utils as geom
             f0, f1 = pl.frames[0].cpu().numpy(), pl.frames[1].cpu().numpy()
             ex = ORBExtractor(n_features=NFEAT)
             mt = DescriptorMatcher("bruteforce-hamming", ratio_threshold=0.75)
@@ -614,12 +615,16 @@ def main():
             ctx1 = V.default_context()
             out["single_frame_ms"] = {
                 "detect_and_compute": med_ms(lambda: ex.detect_and_compute(f0), 20),
+                "detect_and_compute_all_objects": med_ms(lambda: tuple(ex.detect_and_compute(f0)[0]), 20),
                 "detect_and_compute_native_arrays": med_ms(lambda: ctx1.orb_detect_compute(f0, ex.orb.prm), 20),
                 "match_2000x2000": med_ms(lambda: mt.match(d0, d1), 20),
                 "match_native_arrays": med_ms(lambda: ctx1.match_knn2_ratio(d0, d1, 0.75), 20),
                 "extract_features_distributed": med_ms(lambda: ex.extract_features(f0, distributed=True), 10),
-                "note": "median wall ms per call, host numpy in / Python objects out (H2D + kernels + D2H + sync); the *_native_arrays "
-                        "rows stop at numpy arrays (no KeyPoint / DMatch objects)"}
+                "tracker_frame": med_ms(lambda: geom.track_from_last_frame(k0, d0, *ex.detect_and_compute(f1), K, f1.shape), 20),
+                "note": "median wall ms per call, host numpy in / Python objects out (H2D + kernels + D2H + sync); detect_and_compute "
+                        "returns a lazy KeyPoint sequence (objects are built when a caller indexes or iterates it: the *_all_objects "
+                        "row forces all 2000); the *_native_arrays rows stop at numpy arrays; tracker_frame = what a Tracker pays per "
+                        "frame in TRACKING state through the classes: detect_and_compute + track_from_last_frame (tracker.py:87,198-266)"}
         if not args.no_cpu_baseline and world == 1:
             nf = min(args.cpu_frames, nb)
             out["cpu_baseline"] = cpu_baseline(pl.frames[:nf].cpu().numpy(), nf, K)

@@ -212,7 +212,7 @@ typedef struct {
      * d_points [pair][cap][3] by query keypoint (NaN = no map point), d_n_points [pair] = F-RANSAC inliers, d_pose_mask [pair][cap],
      * d_kf_F [pair][9] (may be NULL; NaN with fewer than 8 matches or no model: the reference returns early in both cases). */
     int32_t n_kf_pairs;
-    const int32_t* d_kf_query;  /* [n_kf_pairs] frame index of the query keyframe */
+    const int32_t* d_kf_query;  /* [n_kf_pairs] frame index of the query keyframe, 0 <= index < batch (not checked: device data) */
     const int32_t* d_kf_train;  /* [n_kf_pairs] frame index of the train keyframe */
     const double* d_kf_P1;      /* [n_kf_pairs][12] row-major 3x4 projection matrix of the query keyframe */
     const double* d_kf_P2;      /* [n_kf_pairs][12] ... of the train keyframe */

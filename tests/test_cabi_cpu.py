@@ -120,7 +120,7 @@ def test_keypoints_from_array_fast_path_equals_constructor():
     arr["size"] = 31 * 1.2 ** rng.integers(0, 8, 257); arr["angle"] = rng.uniform(0, 360, 257); arr["response"] = rng.uniform(0, 1e-2, 257)
     arr["octave"] = rng.integers(0, 8, 257); arr["class_id"] = -1
     got = keypoints_from_array(arr)
-    assert isinstance(got, tuple) and len(got) == 257
+    assert len(got) == 257 and len(tuple(got)) == 257
     for k, row in zip(got, arr.tolist()):
         ref = KeyPoint(*row)
         for f in ("pt", "size", "angle", "response", "octave", "class_id"):
@@ -130,3 +130,42 @@ def test_keypoints_from_array_fast_path_equals_constructor():
         assert type(got[0].pt[0]) is float and type(got[0].octave) is int
     assert np.array_equal(keypoints_to_array(got), arr)
     assert keypoints_from_array(arr[:0]) == ()
+
+
+def test_lazy_keypoint_sequence_behaves_like_the_tuple():
+    """orbslam2.types.KeyPointSeq (what detect_and_compute returns): a sequence that creates KeyPoint objects on demand.  Same
+    answers as the materialised tuple for len / index / negative index / slice / iteration / == / +; an object handed out keeps its
+    identity and its attribute writes (they reach keypoints_to_array and points_of); an untouched sequence converts back without
+    creating objects."""
+    from collections.abc import Sequence
+    import vslam_amd as V
+    from orbslam2.types import KeyPointSeq, keypoints_from_array, keypoints_to_array, points_of
+    rng = np.random.default_rng(6)
+    arr = np.zeros(50, V.KP_DTYPE)
+    arr["x"] = rng.uniform(0, 640, 50).astype(np.float32); arr["y"] = rng.uniform(0, 480, 50).astype(np.float32)
+    arr["size"] = 31; arr["angle"] = rng.uniform(0, 360, 50); arr["octave"] = rng.integers(0, 8, 50); arr["class_id"] = -1
+    seq = keypoints_from_array(arr.copy())
+    assert isinstance(seq, (KeyPointSeq, Sequence)) and seq.pristine and len(seq) == 50
+    assert keypoints_to_array(seq) is seq.array                       # no objects, no copy
+    idx = [3, 7, 7, 49, 0]
+    want = np.stack([arr["x"][idx], arr["y"][idx]], axis=1)
+    assert np.array_equal(points_of(seq, idx), want) and points_of(seq, idx).dtype == np.float32 and seq.pristine
+    assert points_of(seq, []).shape == (0, 2)
+    k7 = seq[7]
+    assert k7 is seq[7] and k7 is seq[-43] and not seq.pristine       # identity per index
+    assert k7.pt == (float(arr["x"][7]), float(arr["y"][7])) and k7.octave == int(arr["octave"][7])
+    with pytest.raises(IndexError):
+        seq[50]
+    with pytest.raises(IndexError):
+        seq[-51]
+    k7.class_id = 1234                                                # a caller writes to its object
+    assert np.array_equal(points_of(seq, idx), want)                  # (object path now: same values)
+    back = keypoints_to_array(seq)
+    assert back["class_id"][7] == 1234 and np.array_equal(back["x"], arr["x"]) and np.array_equal(back["octave"], arr["octave"])
+    full = tuple(seq)
+    assert full[7] is k7 and len(full) == 50 and seq[7] is k7          # materialising keeps the handed-out object
+    assert seq[2:5] == full[2:5] and seq[::-1] == full[::-1]
+    assert seq == full and seq != keypoints_from_array(arr.copy())  # (index 7 was written to)
+    assert (seq + (1, 2))[-2:] == (1, 2) and ((1,) + seq)[0] == 1 and len(seq + seq) == 100
+    assert [k.octave for k in seq] == arr["octave"].tolist()
+    assert sum(1 for _ in reversed(seq)) == 50 and full[3] in seq and seq.index(full[3]) == 3

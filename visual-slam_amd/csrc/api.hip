@@ -793,6 +793,7 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
     }
     int n_pairs = io->batch - 1;
     if (n_pairs < 1 || !io->d_match_idx) return MO_OK;
+    if (!io->d_match_dist || !io->d_match_pass) return mo_fail(c, MO_ERR_ARG, "match outputs missing");
     // (query, train) frame of every pair: written once per batch size into a buffer of its own (it was a 5 us launch per call)
     if (c->pair_frames_n < n_pairs) {
         if (c->d_pair_frames) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_pair_frames)); c->d_pair_frames = nullptr; }

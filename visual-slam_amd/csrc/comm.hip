@@ -109,12 +109,13 @@ extern "C" int mo_gather_map_points(mo_ctx* c, const float* d_local, int rows_lo
     HIPCHK(c, hipSetDevice(c->device));
     nccl_comm comm = (nccl_comm)c->comm;
     // 1. per-rank row counts (one int each): all-gather, so that every rank can index the result
-    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, 256);
-    if (rc) return rc;
-    // (the count travels as a kernel argument: an async copy from this function's stack would outlive the variable)
-    hipLaunchKernelGGL(k_store_i32, dim3(1), dim3(1), 0, c->stream, (int32_t*)c->d_tmp, (int32_t)rows_local);
+    // (a word of its own: the gather may run on a side stream beside the next call's kernels, which use the context's other buffers;
+    //  the count travels as a kernel argument: an async copy from this function's stack would outlive the variable)
+    int rc;
+    if (!c->d_comm_cnt) HIPCHK(c, hipMalloc((void**)&c->d_comm_cnt, 256));
+    hipLaunchKernelGGL(k_store_i32, dim3(1), dim3(1), 0, c->stream, c->d_comm_cnt, (int32_t)rows_local);
     HIPCHK(c, hipGetLastError());
-    if ((rc = r.AllGather(c->d_tmp, d_rows_all, 1, NCCL_INT32, comm, c->stream)) != 0) return nccl_fail(c, "ncclAllGather", rc);
+    if ((rc = r.AllGather(c->d_comm_cnt, d_rows_all, 1, NCCL_INT32, comm, c->stream)) != 0) return nccl_fail(c, "ncclAllGather", rc);
     // 2. padded point slabs to the root: one send per rank, `world` receives on the root, one group (point-to-point over xGMI;
     //    the payload is MBs, so this is latency-bound and a ring collective would buy nothing)
     const size_t slab = (size_t)rows_max * cap * 3;

@@ -126,6 +126,7 @@ struct mo_ctx {
 
     // RCCL communicator of the sharded batched mode (comm.hip); null until mo_comm_init
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
+    int32_t* d_comm_cnt = nullptr;  // this rank's row count for mo_gather_map_points' all-gather
 
     uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned host staging of small host-API results
     int32_t* d_pair_frames = nullptr; int pair_frames_n = 0, pair_frames_split = 0;  // mo_dev_frontend_batch: qf[i] = i, tf[i] = i + 1

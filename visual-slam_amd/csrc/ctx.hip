@@ -113,7 +113,7 @@ extern "C" void mo_destroy(mo_ctx* c) {
     mo_comm_destroy(c);
     free_plan_buffers(c);
     void* bufs[] = {c->d_in, c->d_gray, c->d_flags, c->d_kps, c->d_desc, c->d_counts, c->d_mq, c->d_mt,
-                    c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp, c->d_pair_frames, c->d_dtodo};
+                    c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp, c->d_pair_frames, c->d_dtodo, c->d_comm_cnt};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (TimingSet& t : c->tsets) {

@@ -15,14 +15,12 @@ matches) when matching or geometry is insufficient, R 3x3 / t 3x1 float64 on suc
 import numpy as np
 
 from . import utils as _geom
+from .types import points_of
 
 
 def _pixels(keypoints, indices):
     """(N, 2) float32 pixel coordinates of the selected keypoints."""
-    out = np.empty((len(indices), 2), np.float32)
-    for row, i in enumerate(indices):
-        out[row] = keypoints[i].pt
-    return out
+    return points_of(keypoints, indices)
 
 
 class MapInitializer:

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 import vslam_amd
-from .types import DMatch
+from .types import DMatch, points_of
 
 
 class _NativeBFMatcher:
@@ -63,12 +63,18 @@ class DescriptorMatcher:
     def filter_matches_by_geometric_distance(self, keypoints1, keypoints2, matches, threshold_percent, image_shape):
         height, width = image_shape[:2]
         limit = ((width + height) / 2.0) * threshold_percent
-        kept = []
-        for m in matches:
-            a, b = keypoints1[m.queryIdx].pt, keypoints2[m.trainIdx].pt
-            if math.hypot(b[0] - a[0], b[1] - a[1]) <= limit:
-                kept.append(m)
-        return kept
+        if not matches:
+            return []
+        # the reference's per-match math.hypot(dx, dy) <= limit on Python floats (float64 of the float32 coordinates): vectorised,
+        # with the matches within rounding distance of the limit decided by math.hypot itself
+        a = points_of(keypoints1, [m.queryIdx for m in matches]).astype(np.float64)
+        b = points_of(keypoints2, [m.trainIdx for m in matches]).astype(np.float64)
+        dx, dy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1]
+        dist = np.hypot(dx, dy)
+        near = dist <= limit
+        for i in np.flatnonzero(np.abs(dist - limit) <= 1e-9 * max(limit, 1.0)).tolist():
+            near[i] = math.hypot(dx[i], dy[i]) <= limit
+        return [m for m, ok in zip(matches, near.tolist()) if ok]
 
     def filter_matches_by_distance(self, matches, distance_threshold=None):
         if not matches:
@@ -83,8 +89,8 @@ class DescriptorMatcher:
         fewer than 8 matches are returned unfiltered with an all-true mask, like the reference."""
         if len(matches) < 8:
             return matches, np.ones(len(matches), dtype=bool)
-        points1 = np.float32([keypoints1[m.queryIdx].pt for m in matches])
-        points2 = np.float32([keypoints2[m.trainIdx].pt for m in matches])
+        points1 = points_of(keypoints1, [m.queryIdx for m in matches])
+        points2 = points_of(keypoints2, [m.trainIdx for m in matches])
         F, mask = vslam_amd.default_context().find_fundamental(points1, points2, thr_px=threshold, prob=0.99)
         if F is None:  # cv2 returns mask None here and the reference would raise on mask.ravel(); no model -> no inliers
             return [], np.zeros(len(matches), dtype=bool)

@@ -99,8 +99,9 @@ def triangulate_new_map_points(prev_keypoints, prev_descriptors, cur_keypoints, 
     q = np.flatnonzero(keep & two)
     if len(q) < 8:
         return np.zeros((0, 3), np.float32), []
-    points1 = np.float32([prev_keypoints[i].pt for i in q])
-    points2 = np.float32([cur_keypoints[idx[i, 0]].pt for i in q])
+    from .types import points_of
+    points1 = points_of(prev_keypoints, q)
+    points2 = points_of(cur_keypoints, idx[q, 0])
     F, mask = calculate_fundamental_matrix(points1, points2, threshold)
     if F is None:
         return np.zeros((0, 3), np.float32), []
