@@ -169,3 +169,11 @@ def test_lazy_keypoint_sequence_behaves_like_the_tuple():
     assert (seq + (1, 2))[-2:] == (1, 2) and ((1,) + seq)[0] == 1 and len(seq + seq) == 100
     assert [k.octave for k in seq] == arr["octave"].tolist()
     assert sum(1 for _ in reversed(seq)) == 50 and full[3] in seq and seq.index(full[3]) == 3
+
+
+def test_keypoints_as_plain_tuple_on_request(monkeypatch):
+    import vslam_amd as V
+    from orbslam2.types import keypoints_from_array
+    monkeypatch.setenv("VSLAM_AMD_KEYPOINTS", "tuple")
+    got = keypoints_from_array(np.zeros(3, V.KP_DTYPE))
+    assert type(got) is tuple and len(got) == 3

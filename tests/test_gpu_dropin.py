@@ -25,7 +25,8 @@ def test_extractor_matcher_like_test_matcher_py():
     ex = ORBExtractor(n_features=2000, scale_factor=1.2, n_levels=8, ini_threshold=20, min_threshold=7)
     kp1, d1 = ex.detect_and_compute(a)
     kp2, d2 = ex.detect_and_compute(b)
-    assert isinstance(kp1, tuple) and d1.shape == (len(kp1), 32) and d1.dtype == np.uint8
+    from collections.abc import Sequence
+    assert isinstance(kp1, Sequence) and isinstance(tuple(kp1), tuple) and d1.shape == (len(kp1), 32) and d1.dtype == np.uint8
     m = DescriptorMatcher(matcher_type='bruteforce-hamming', ratio_threshold=0.85)
     good = m.match(d1, d2, ratio_test=True)
     assert len(good) > 500

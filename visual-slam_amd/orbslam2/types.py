@@ -2,6 +2,7 @@
 
 When cv2 is importable the real classes are used (the caller's drawKeypoints / drawMatches need them); otherwise
 duck-typed objects with the same attributes and constructor argument order."""
+import os as _os
 from collections.abc import Sequence as _Sequence
 
 try:  # pragma: no cover - cv2 is absent in the build container
@@ -129,7 +130,10 @@ class KeyPointSeq(_Sequence):
 
 
 def keypoints_from_array(arr):
-    """structured mo_keypoint array -> what detectAndCompute returns (cv2: a tuple of KeyPoint; here the lazy KeyPointSeq)"""
+    """structured mo_keypoint array -> what detectAndCompute returns (cv2: a tuple of KeyPoint; here the lazy KeyPointSeq, or the
+    plain tuple with VSLAM_AMD_KEYPOINTS=tuple for a caller that insists on the type)"""
+    if _os.environ.get("VSLAM_AMD_KEYPOINTS", "lazy").lower() == "tuple":
+        return _materialize(arr)
     return KeyPointSeq(arr)
 
 
