@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 import vslam_amd
-from .types import DMatch, points_of
+from .types import DMatch, dmatches_from_arrays, points_of
 
 
 class _NativeBFMatcher:
@@ -55,7 +55,7 @@ class DescriptorMatcher:
         idx, dist, keep = vslam_amd.default_context().match_knn2_ratio(descriptors1, descriptors2, ratio)
         # survivors as Python scalars in three bulk conversions (numpy scalar reads per match were a third of this call)
         q = np.nonzero(keep)[0]
-        return [DMatch(a, b, 0, d) for a, b, d in zip(q.tolist(), idx[q, 0].tolist(), dist[q, 0].astype(np.float64).tolist())]
+        return dmatches_from_arrays(q, idx[q, 0], dist[q, 0])
 
     def match_with_mask(self, descriptors1, descriptors2, mask):
         raise NotImplementedError("match_with_mask has no caller in the reference (dead code, SURVEY.md 2.1)")

@@ -152,3 +152,20 @@ def points_of(kps, indices):
         a = kps.array[np.asarray(indices, dtype=np.intp)]
         return np.stack([a["x"], a["y"]], axis=1).astype(np.float32).reshape(-1, 2)
     return np.float32([kps[i].pt for i in indices]).reshape(-1, 2)
+
+
+def dmatches_from_arrays(query, train, distance):
+    """three equal-length arrays -> list of DMatch(queryIdx, trainIdx, 0, distance), Python scalars in bulk conversions; the
+    stand-in class gets its slots filled directly (a quarter less time than 1000 __init__ calls with their int() / float())"""
+    import numpy as np
+    q, t = np.asarray(query).tolist(), np.asarray(train).tolist()
+    d = np.asarray(distance, dtype=np.float64).tolist()
+    if HAVE_CV2:
+        return [DMatch(a, b, 0, c) for a, b, c in zip(q, t, d)]
+    new, out = object.__new__, []
+    append = out.append
+    for a, b, c in zip(q, t, d):
+        m = new(DMatch)
+        m.queryIdx = a; m.trainIdx = b; m.imgIdx = 0; m.distance = c
+        append(m)
+    return out

@@ -62,7 +62,7 @@ def track_from_last_frame(last_keypoints, last_descriptors, keypoints, descripto
     cv2.findEssentialMat(RANSAC, 0.999, 1.0) -> cv2.recoverPose.  Tracker calls cv2 directly for the last two, so the caller
     needs this one-line replacement.  -> (success, T 4x4 float64, inlier matches as DMatch list); like the
     reference it fails with fewer than 8 filtered matches or without a valid essential matrix."""
-    from .types import DMatch, keypoints_to_array
+    from .types import dmatches_from_arrays, keypoints_to_array
     if last_keypoints is None or last_descriptors is None or descriptors is None:
         return False, None, []
     h, w = image_shape[:2]
@@ -74,7 +74,9 @@ def track_from_last_frame(last_keypoints, last_descriptors, keypoints, descripto
     T = np.eye(4)
     T[:3, :3] = r["R"]
     T[:3, 3] = r["t"].reshape(3)
-    inliers = [DMatch(int(q), int(t), 0, float(d)) for (q, t), d, ok in zip(r["sel"], r["sel_dist"], r["inlier"]) if ok]
+    ok = np.asarray(r["inlier"]).astype(bool).reshape(-1)
+    sel = np.asarray(r["sel"]).reshape(-1, 2)[ok]
+    inliers = dmatches_from_arrays(sel[:, 0], sel[:, 1], np.asarray(r["sel_dist"]).reshape(-1)[ok])
     return True, T, inliers
 
 
@@ -93,7 +95,7 @@ def triangulate_new_map_points(prev_keypoints, prev_descriptors, cur_keypoints, 
     0.8 ratio test -> cv2.findFundamentalMat(FM_RANSAC, 3.0) -> keep inliers -> triangulate with the two keyframe poses.
     pose1 / pose2: 4x4 keyframe poses.  -> (points_3d (N, 3) float32, inlier matches as DMatch list); ([], []) when fewer than
     8 ratio-test matches or no fundamental matrix is found (the reference returns early in both cases)."""
-    from .types import DMatch
+    from .types import dmatches_from_arrays
     idx, dist, keep = vslam_amd.default_context().match_knn2_ratio(np.uint8(prev_descriptors), np.uint8(cur_descriptors), ratio)
     two = idx[:, 1] >= 0  # local_mapper.py:123: only pairs with two neighbours take part
     q = np.flatnonzero(keep & two)
@@ -109,5 +111,5 @@ def triangulate_new_map_points(prev_keypoints, prev_descriptors, cur_keypoints, 
     P1 = compute_projection_matrix(pose1[:3, :3], pose1[:3, 3], camera_matrix)
     P2 = compute_projection_matrix(pose2[:3, :3], pose2[:3, 3], camera_matrix)
     pts = convert_to_3d_points(triangulate_points(points1[m], points2[m], P1, P2))
-    matches = [DMatch(int(i), int(idx[i, 0]), 0, float(dist[i, 0])) for i in q[m]]
+    matches = dmatches_from_arrays(q[m], idx[q[m], 0], dist[q[m], 0])
     return pts, matches
