@@ -256,7 +256,7 @@ int mo_gather_map_points(mo_ctx*, const float* d_local, int rows_local, int rows
  * and clears it.  bit 0 (1): a level's internal keypoint slot overflowed (response ties at the quota cut);
  * bit 1 (2): a frame produced more keypoints than `cap` - its rows are truncated to cap while d_counts[frame] holds the
  * number it needed (so d_counts can EXCEED cap: clamp before indexing, or retry with cap >= max(d_counts));
- * bit 2 (4): more than 2048 local maxima in one grid cell (mo_orb_grid_good_features / MO_DETECT_GRID).
+ * bit 2 (4): not raised any more (rounds 2 - 3: more than 2048 local maxima in one grid cell; such cells are now processed in rounds).
  * Returns MO_OK when no bit is set, MO_ERR_CAPACITY otherwise. */
 int mo_dev_status(mo_ctx*, int32_t flags[4]);
 

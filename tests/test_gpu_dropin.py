@@ -689,3 +689,41 @@ def test_ragged_batch_with_empty_and_sparse_frames(detector):
                 assert np.linalg.norm(P[i, :9].reshape(3, 3) - o["R"]) < 1e-4 and abs(int(NP[i]) - o["n_good"]) <= 2, i
         assert np.isnan(P[1]).all() and np.isnan(P[2]).all()          # both pairs of the flat frame
         assert np.isfinite(P[0]).all() and NP[0] > 50                 # the textured pair before them is a normal pair
+
+
+@pytest.mark.parametrize("name", ["checker3", "checker5_fullhd", "noise_large", "texture_fullhd"])
+def test_grid_cells_with_more_local_maxima_than_one_sort_holds(name):
+    """k_gftt_cell sorts up to 2048 local maxima of a cell at once; a cell with more (plateaus of a synthetic pattern - every pixel of
+    a 3-px checkerboard ties -, the 240 x 135 cells of a Full-HD frame) is taken in rounds of the 2048 strongest remaining keys
+    (bisection on the 64-bit (value, address) key).  Corners, kept indices and descriptors equal the oracle's one long sorted list
+    (rounds 1 - 2 refused such frames with MO_ERR_CAPACITY).  Found by tools/fuzz_parity.py."""
+    import vslam_amd as V
+    from oracle import orb_oracle as O
+    from tests.helpers import synthetic_frame
+    rng = np.random.default_rng(3)
+    if name == "checker3":
+        yy, xx = np.mgrid[0:236, 0:663]
+        img = (((yy // 3 + xx // 3) & 1) * 255).astype(np.uint8)
+    elif name == "checker5_fullhd":
+        yy, xx = np.mgrid[0:1080, 0:1920]
+        img = (((yy // 5 + xx // 5) & 1) * 200 + 20).astype(np.uint8)
+    elif name == "noise_large":
+        img = rng.integers(0, 256, size=(1080, 1920), dtype=np.uint8)
+    else:
+        img = synthetic_frame(77, 1920, 1080)
+    h, w = img.shape
+    ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=1)
+    O.lib().orc_set_variant(0, 0)
+    try:
+        for nf in (2000, 6400):
+            exy = O.grid_good_features(img, nf)
+            assert np.array_equal(ctx.grid_good_features(img, nf), exy), nf
+            xy, kept, d = ctx.grid_detect_compute(img, V.orb_params(nfeatures=nf), nf)
+            assert np.array_equal(xy, exy)
+            k = np.zeros(len(exy), V.KP_DTYPE)
+            k["x"], k["y"], k["size"], k["angle"], k["class_id"] = exy[:, 0], exy[:, 1], 31, -1, -1
+            ekept, ed = O.compute(img, O.params(nfeatures=nf), k)
+            assert np.array_equal(kept, ekept) and (not len(ekept) or np.array_equal(d, ed))
+    finally:
+        ctx.close()
+        O.lib().orc_set_variant(1, 0)

@@ -340,10 +340,7 @@ static int gftt_run(mo_ctx* c, const uint8_t* img, int w, int h, int stride, int
     int hn[64];
     HIPCHK(c, hipMemcpyAsync(hxy.data(), d_xy, xy_b, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hn, d_n, sizeof(hn), hipMemcpyDeviceToHost, c->stream));
-    int f[4];
-    HIPCHK(c, hipMemcpyAsync(f, host_flags(c), sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (f[0] & 4) return mo_fail(c, MO_ERR_CAPACITY, "more than 2048 local maxima in one grid cell");
     int n = 0;
     if (xy)
         for (int cell = 0; cell < 64; cell++)
@@ -406,7 +403,6 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     HIPCHK(c, hipMemcpyAsync(hs + h_kept, d_kept, (size_t)slots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(hs + h_desc, d_desc, (size_t)slots * 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (((const int*)hs)[0] & 4) return mo_fail(c, MO_ERR_CAPACITY, "more than 2048 local maxima in one grid cell");
     const int* hn = (const int*)(hs + h_n);
     const float* hxy = (const float*)(hs + h_xy);
     int n = 0;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ g
     }
 }
 
-#define GF_CAP 2048       // local maxima per cell that can be sorted (bit 2 of the flag word beyond)
+#define GF_CAP 2048       // local maxima per cell sorted at once (a cell with more is taken in rounds of the GF_CAP strongest remaining)
 #define GF_MAXCORNERS 256
 
 #define GF_TILE_MAX 5248  // floats of the cell + 1-px ring held in LDS ((80 + 2) x (60 + 2) = 5084 at 640 x 480); larger cells read the map from global memory
@@ -227,74 +227,138 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
         __syncthreads();
     }
     __syncthreads();
-    int n = s_n;
-    if (n > GF_CAP) {
-        if (tid == 0) atomicOr(&flags[0], 4);
-        n = GF_CAP;
-    }
+    const int n_all = s_n;  // every local maximum of the cell (the key array holds the first min(n_all, cap) of them)
+    const int lim = min(max_corners > 0 ? max_corners : GF_MAXCORNERS, GF_MAXCORNERS);
+    int nacc = 0;           // corners accepted so far (maintained by wavefront 0, published through s_n between rounds)
     // 3. sort descending by (value, address): bitonic network on the next power of two (padding keys = 0 sink to the end)
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int i = n + tid; i < np2; i += 256) s_key[i] = 0ull;
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < np2; i += 256) {
-                int l = i ^ j;
-                if (l > i) {
-                    unsigned long long a = s_key[i], b = s_key[l];
-                    bool desc = (i & k) == 0;
-                    if (desc ? a < b : a > b) { s_key[i] = b; s_key[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
     // 4. greedy minimum-distance pick by one wavefront, 64 candidates of the sorted list at a time, one per lane: a lane first
     //    drops its candidate if it lies within min_dist of a corner accepted in earlier batches, then the surviving lanes are
     //    resolved in list order - the lowest one is accepted and knocks out the later lanes within min_dist of it.  The accepted
     //    set and its order are those of the sequential loop (a candidate is accepted iff no EARLIER accepted corner is near).
-    if (wv == 0) {
-        const float md2 = (float)(min_dist * min_dist);
-        const bool use_dist = min_dist >= 1.0;
-        int nacc = 0;
-        const int lim = min(max_corners > 0 ? max_corners : GF_MAXCORNERS, GF_MAXCORNERS);
-        for (int i0 = 0; i0 < n && nacc < lim; i0 += 64) {  // wave-uniform
-            const int i = i0 + lane;
-            bool alive = i < n;
-            float fx = 0.f, fy = 0.f;
-            if (alive) {
-                const unsigned pos = (unsigned)(s_key[i] & 0xFFFFFFFFull);
-                const int yy = pos / w, xx = pos - yy * w;
-                fx = (float)xx; fy = (float)yy;
-                if (use_dist)
-                    for (int j = 0; j < nacc; j++) {  // accepted corners: wave-uniform LDS reads (broadcast)
-                        const float dx = fx - s_ax[j], dy = fy - s_ay[j];
-                        if (dx * dx + dy * dy < md2) { alive = false; break; }
+    auto sort_and_pick = [&](int n) {  // block-uniform n <= GF_CAP keys in s_key
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int i = n + tid; i < np2; i += 256) s_key[i] = 0ull;
+        __syncthreads();
+        for (int k = 2; k <= np2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < np2; i += 256) {
+                    int l = i ^ j;
+                    if (l > i) {
+                        unsigned long long a = s_key[i], b = s_key[l];
+                        bool desc = (i & k) == 0;
+                        if (desc ? a < b : a > b) { s_key[i] = b; s_key[l] = a; }
                     }
-            }
-            unsigned long long live = __ballot(alive);
-            while (live && nacc < lim) {  // wave-uniform
-                const int l = __ffsll((long long)live) - 1;
-                const float ax = __shfl(fx, l, 64), ay = __shfl(fy, l, 64);
-                if (lane == 0) {
-                    s_ax[nacc] = ax; s_ay[nacc] = ay;
-                    out_xy[((size_t)cell * lim + nacc) * 2] = ax;
-                    out_xy[((size_t)cell * lim + nacc) * 2 + 1] = ay;
                 }
-                nacc++;
-                if (lane == l) alive = false;
-                else if (alive && use_dist) {
-                    const float dx = fx - ax, dy = fy - ay;
-                    if (dx * dx + dy * dy < md2) alive = false;
-                }
-                live = __ballot(alive);
+                __syncthreads();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_ax / s_ay written by lane 0 are read by all lanes in the next batch
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (wv == 0) {
+            const float md2 = (float)(min_dist * min_dist);
+            const bool use_dist = min_dist >= 1.0;
+            for (int i0 = 0; i0 < n && nacc < lim; i0 += 64) {  // wave-uniform
+                const int i = i0 + lane;
+                bool alive = i < n;
+                float fx = 0.f, fy = 0.f;
+                if (alive) {
+                    const unsigned pos = (unsigned)(s_key[i] & 0xFFFFFFFFull);
+                    const int yy = pos / w, xx = pos - yy * w;
+                    fx = (float)xx; fy = (float)yy;
+                    if (use_dist)
+                        for (int j = 0; j < nacc; j++) {  // accepted corners: wave-uniform LDS reads (broadcast)
+                            const float dx = fx - s_ax[j], dy = fy - s_ay[j];
+                            if (dx * dx + dy * dy < md2) { alive = false; break; }
+                        }
+                }
+                unsigned long long live = __ballot(alive);
+                while (live && nacc < lim) {  // wave-uniform
+                    const int l = __ffsll((long long)live) - 1;
+                    const float ax = __shfl(fx, l, 64), ay = __shfl(fy, l, 64);
+                    if (lane == 0) {
+                        s_ax[nacc] = ax; s_ay[nacc] = ay;
+                        out_xy[((size_t)cell * lim + nacc) * 2] = ax;
+                        out_xy[((size_t)cell * lim + nacc) * 2 + 1] = ay;
+                    }
+                    nacc++;
+                    if (lane == l) alive = false;
+                    else if (alive && use_dist) {
+                        const float dx = fx - ax, dy = fy - ay;
+                        if (dx * dx + dy * dy < md2) alive = false;
+                    }
+                    live = __ballot(alive);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_ax / s_ay written by lane 0 are read by all lanes in the next batch
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
         }
-        if (lane == 0) out_n[cell] = nacc;
+    };
+    if (n_all <= GF_CAP) {
+        sort_and_pick(n_all);
+    } else {
+        // More local maxima than the key array sorts at once (plateaus of a synthetic pattern; the large cells of a Full-HD frame of
+        // dense texture): the candidates are taken in rounds of the GF_CAP largest remaining keys.  Keys are distinct (the address is
+        // part of them), so "the GF_CAP largest keys below `up`" is the set lo <= key < up for the one lo a bisection over the
+        // 64-bit key finds (each probe counts the keys of the cell in a range: a scan of the map in global memory).  Rare and slow,
+        // but the same corners in the same order as one long sorted list.
+        auto scan = [&](unsigned long long lo, unsigned long long up, bool list) -> int {  // keys in [lo, up): count, or list into s_key
+            int cnt = 0;
+            for (int i = tid; i < n_in; i += 256) {
+                const int yy = ya + i / cw2, xx = xa + i % cw2;
+                const float* p = eig + (size_t)yy * w + xx;
+                const float v = p[0];
+                if (!(v > thr)) continue;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx);
+                if (key < lo || key >= up) continue;
+                float mx = v;
+#pragma unroll
+                for (int j = -1; j <= 1; j++)
+#pragma unroll
+                    for (int k = -1; k <= 1; k++) {
+                        float q = p[j * w + k];
+                        q = q > thr ? q : 0.f;
+                        mx = fmaxf(mx, q);
+                    }
+                if (v == mx) {
+                    if (list) { const int slot = atomicAdd(&s_n, 1); if (slot < GF_CAP) s_key[slot] = key; }
+                    cnt++;
+                }
+            }
+            if (list) return 0;
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            __syncthreads();  // (s_red: the previous probe's readers are done)
+            if (lane == 0) s_red[wv] = __int_as_float(cnt);
+            __syncthreads();
+            return __float_as_int(s_red[0]) + __float_as_int(s_red[1]) + __float_as_int(s_red[2]) + __float_as_int(s_red[3]);
+        };
+        unsigned long long up = ((unsigned long long)__float_as_uint(m) + 1ull) << 32;  // above every key (m: the cell maximum)
+        int remaining = n_all;
+        while (remaining > 0) {  // block-uniform
+            unsigned long long lo = 0ull;
+            if (remaining > GF_CAP) {
+                unsigned long long a = (unsigned long long)__float_as_uint(thr) << 32, b = up;  // keys in [a, up) > GF_CAP >= keys in [b, up)
+                while (b - a > 1ull) {
+                    const unsigned long long mid = a + ((b - a) >> 1);
+                    if (scan(mid, up, false) <= GF_CAP) b = mid; else a = mid;
+                }
+                lo = b;
+            }
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            scan(lo, up, true);
+            __syncthreads();
+            const int nr = min(s_n, GF_CAP);  // == min(remaining, GF_CAP)
+            sort_and_pick(nr);
+            if (tid == 0) s_n = nacc;  // (thread 0 is lane 0 of wavefront 0)
+            __syncthreads();
+            const int acc_all = s_n;
+            __syncthreads();
+            if (acc_all >= lim || nr <= 0) break;
+            remaining -= nr;
+            up = lo;
+        }
     }
+    if (wv == 0 && lane == 0) out_n[cell] = nacc;
 }
 
 // batch frames [batch][h][w] -> d_eig [batch][h][w], d_xy [batch][64][per_cell][2], d_n [batch][64 + 2] (the two extra counters
