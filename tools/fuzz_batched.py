@@ -34,12 +34,12 @@ def frames_of(rng, nb, w, h):
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=400.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.Generator(np.random.PCG64(args.seed))
     dev = torch.device("cuda", 0)
     st = torch.cuda.Stream(device=dev)

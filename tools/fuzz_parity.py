@@ -43,12 +43,12 @@ def same_kps(a, b):
     return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=400.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = np.random.Generator(np.random.PCG64(args.seed))
     ctx = V.Context(device=0, max_w=1000, max_h=800, max_batch=5)
     bad, done, t0 = 0, 0, time.time()
