@@ -150,30 +150,40 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     // read the map from global memory up to ten times per pixel (maximum, threshold, 3x3 dilation)
     const int tw = cw + 2, th = ch + 2;
     const bool in_lds = tw * th <= GF_TILE_MAX;  // block-uniform
-    if (in_lds) {  // GF_LD loads per thread in flight before the first store (a plain loop makes one global round trip per value)
-        constexpr int GF_LD = 8;
+    float m = -FLT_MAX;
+    if (in_lds) {
+        // every load of a thread in flight before the first store (a plain loop makes one global round trip per value; round 3's first
+        // form kept 8 in flight: three round trips for the 5084 floats of a 640 x 480 cell, 12.7 k of the workgroup's 61 k cycles).
+        // The cell maximum (minMaxLoc with the cell mask) is taken from the registers on the way: no second pass over the tile.
+        constexpr int GF_LD = (GF_TILE_MAX + 255) / 256;
         const uint32_t inv_tw = 0xFFFFFFFFu / (uint32_t)tw + 1u;
-        for (int i0 = tid; i0 < tw * th; i0 += 256 * GF_LD) {
-            float v[GF_LD];
+        float v[GF_LD];
 #pragma unroll
-            for (int u = 0; u < GF_LD; u++) {
-                const int i = min(i0 + u * 256, tw * th - 1), r = (int)__umulhi((uint32_t)i, inv_tw), c = i - r * tw;
+        for (int u = 0; u < GF_LD; u++) {
+            const int i = tid + u * 256;
+            if (i < tw * th) {
+                const int r = (int)__umulhi((uint32_t)i, inv_tw), c = i - r * tw;
                 const int yy = min(max(y0 - 1 + r, 0), h - 1), xx = min(max(x0 - 1 + c, 0), w - 1);
                 v[u] = eig[(size_t)yy * w + xx];
             }
+        }
 #pragma unroll
-            for (int u = 0; u < GF_LD; u++)
-                if (i0 + u * 256 < tw * th) s_tile[i0 + u * 256] = v[u];
+        for (int u = 0; u < GF_LD; u++) {
+            const int i = tid + u * 256;
+            if (i < tw * th) {
+                s_tile[i] = v[u];
+                const int r = (int)__umulhi((uint32_t)i, inv_tw), c = i - r * tw;
+                if (r >= 1 && r <= ch && c >= 1 && c <= cw) m = fmaxf(m, v[u]);
+            }
+        }
+    } else {
+        for (int i = tid; i < cw * ch; i += 256) {
+            const int r = i / cw, c = i - r * cw;
+            m = fmaxf(m, eig[(size_t)(y0 + r) * w + x0 + c]);
         }
     }
     if (tid == 0) s_n = 0;
-    __syncthreads();
     // 1. cell maximum (minMaxLoc with the cell mask)
-    float m = -FLT_MAX;
-    for (int i = tid; i < cw * ch; i += 256) {
-        const int r = i / cw, c = i - r * cw;
-        m = fmaxf(m, in_lds ? s_tile[(r + 1) * tw + c + 1] : eig[(size_t)(y0 + r) * w + x0 + c]);
-    }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) s_red[wv] = m;
     __syncthreads();
@@ -236,6 +246,17 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     //    resolved in list order - the lowest one is accepted and knocks out the later lanes within min_dist of it.  The accepted
     //    set and its order are those of the sequential loop (a candidate is accepted iff no EARLIER accepted corner is near).
     auto sort_and_pick = [&](int n) {  // block-uniform n <= GF_CAP keys in s_key
+        if (n <= 256) {
+            // short list (typical: 50 - 120 keys): every key counts the keys above it - its position in the descending list, keys
+            // are distinct - out of broadcast LDS reads: one pass and two barriers instead of the 28 barrier-separated steps of
+            // the network on 128 keys (13.8 k of the workgroup's 61 k cycles)
+            const unsigned long long mine = tid < n ? s_key[tid] : 0ull;
+            int rank = 0;
+            for (int j = 0; j < n; j++) rank += s_key[j] > mine ? 1 : 0;
+            __syncthreads();
+            if (tid < n) s_key[rank] = mine;
+            __syncthreads();
+        } else {
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         for (int i = n + tid; i < np2; i += 256) s_key[i] = 0ull;
@@ -252,44 +273,43 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
                 }
                 __syncthreads();
             }
+        }
         if (wv == 0) {
             const float md2 = (float)(min_dist * min_dist);
             const bool use_dist = min_dist >= 1.0;
+            __builtin_amdgcn_s_setprio(3);  // one dependent chain against the other workgroups' wavefronts on this SIMD: take the issue slots first
+            const uint32_t inv_w = 0xFFFFFFFFu / (uint32_t)w + 1u;  // pos / w == mulhi(pos, inv_w): pos < w * h < 2^32 / w for every supported size
+            const bool exact_div = (unsigned long long)w * h * w < (1ull << 32);
             for (int i0 = 0; i0 < n && nacc < lim; i0 += 64) {  // wave-uniform
+                // straight-line code, scalar loop control: one wavefront works here alone (nothing hides a taken branch or an LDS
+                // round trip), and the first form's per-lane early exits cost ~500 cycles per accepted corner
                 const int i = i0 + lane;
                 bool alive = i < n;
-                float fx = 0.f, fy = 0.f;
-                if (alive) {
-                    const unsigned pos = (unsigned)(s_key[i] & 0xFFFFFFFFull);
-                    const int yy = pos / w, xx = pos - yy * w;
-                    fx = (float)xx; fy = (float)yy;
-                    if (use_dist)
-                        for (int j = 0; j < nacc; j++) {  // accepted corners: wave-uniform LDS reads (broadcast)
-                            const float dx = fx - s_ax[j], dy = fy - s_ay[j];
-                            if (dx * dx + dy * dy < md2) { alive = false; break; }
-                        }
-                }
+                const unsigned pos = (unsigned)(s_key[min(i, n - 1)] & 0xFFFFFFFFull);
+                const int yy = exact_div ? (int)__umulhi(pos, inv_w) : (int)(pos / (unsigned)w), xx = (int)pos - yy * w;
+                const float fx = (float)xx, fy = (float)yy;
+                nacc = __builtin_amdgcn_readfirstlane(nacc);  // (wave-uniform by construction)
+                if (use_dist)
+                    for (int j = 0; j < nacc; j++) {  // corners accepted in earlier batches: broadcast LDS reads, no early exit
+                        const float dx = fx - s_ax[j], dy = fy - s_ay[j];
+                        alive = alive & !(dx * dx + dy * dy < md2);
+                    }
                 unsigned long long live = __ballot(alive);
                 while (live && nacc < lim) {  // wave-uniform
-                    const int l = __ffsll((long long)live) - 1;
-                    const float ax = __shfl(fx, l, 64), ay = __shfl(fy, l, 64);
-                    if (lane == 0) {
-                        s_ax[nacc] = ax; s_ay[nacc] = ay;
-                        out_xy[((size_t)cell * lim + nacc) * 2] = ax;
-                        out_xy[((size_t)cell * lim + nacc) * 2 + 1] = ay;
-                    }
+                    const int l = __ffsll((long long)live) - 1;  // wave-uniform: v_readlane instead of two LDS-routed shuffles
+                    const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fx), l));
+                    const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fy), l));
+                    if (lane == 0) { s_ax[nacc] = ax; s_ay[nacc] = ay; }  // (the corners leave for global memory after the last round)
                     nacc++;
-                    if (lane == l) alive = false;
-                    else if (alive && use_dist) {
-                        const float dx = fx - ax, dy = fy - ay;
-                        if (dx * dx + dy * dy < md2) alive = false;
-                    }
+                    const float dx = fx - ax, dy = fy - ay;
+                    alive = alive & (lane != l) & !(use_dist & (dx * dx + dy * dy < md2));
                     live = __ballot(alive);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_ax / s_ay written by lane 0 are read by all lanes in the next batch
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
+            __builtin_amdgcn_s_setprio(0);
         }
     };
     if (n_all <= GF_CAP) {
@@ -358,7 +378,10 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
             up = lo;
         }
     }
-    if (wv == 0 && lane == 0) out_n[cell] = nacc;
+    if (wv == 0) {  // accepted corners in acceptance order: coalesced stores out of the LDS list (lane 0's writes are fenced above)
+        for (int j = lane; j < 2 * nacc; j += 64) out_xy[(size_t)cell * lim * 2 + j] = (j & 1) ? s_ay[j >> 1] : s_ax[j >> 1];
+        if (lane == 0) out_n[cell] = nacc;
+    }
 }
 
 // batch frames [batch][h][w] -> d_eig [batch][h][w], d_xy [batch][64][per_cell][2], d_n [batch][64 + 2] (the two extra counters
