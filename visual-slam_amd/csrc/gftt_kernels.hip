@@ -26,62 +26,100 @@ __device__ __forceinline__ int gf_reflect101(int p, int len) {
 // products of gradients that are multiples of 1 / 3060 up to rounding, i.e. zero or between 2^-24 and 2^-1 in magnitude with 24-bit
 // mantissas - nine of them add up exactly in 53 bits whatever the order, so the result is the oracle's bit for bit.
 __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ gray, int w, int h, float* __restrict__ eig) {
-    __shared__ uint8_t s_px[(ME_TH + 4) * (ME_TW + 4)];
+    __shared__ __attribute__((aligned(16))) uint8_t s_px[(ME_TH + 4) * (ME_TW + 8)];  // (pitch ME_TW + 8 in the dword path, ME_TW + 4 in the byte path)
     __shared__ float s_dx[(ME_TH + 2) * (ME_TW + 2)], s_dy[(ME_TH + 2) * (ME_TW + 2)];
     const int tx0 = blockIdx.x * ME_TW, ty0 = blockIdx.y * ME_TH, tid = threadIdx.x;
     gray += (size_t)blockIdx.z * w * h;  // frame of a batch (dense frames, dense maps)
     eig += (size_t)blockIdx.z * w * h;
-    // The Sobel window of a REFLECTED gradient position is reflected again, which is not one reflection of the pixel coordinate.
-    // Away from the image border both agree: interior tiles (block-uniform test) stage plain coordinates through LDS, border tiles
-    // evaluate the double reflection directly from global memory.
+    // The Sobel window of a REFLECTED gradient position is reflected again, which is not one reflection of the pixel coordinate:
+    // tiles that touch the image border (block-uniform test; 31 % of the tiles of a 640 x 480 frame) compute the in-image gradients
+    // from pixels staged with ONE reflection of the pixel coordinate - what Sobel applies at an in-image position - and copy them to
+    // the ring just outside the image (the box filter's BORDER_REFLECT_101 of the covariance maps: gradient(-1) = gradient(1)).
+    // (Rounds 1 - 3 evaluated the double reflection of border tiles from global memory, nine reflected byte reads per gradient position:
+    //  0.464 against 0.474 ms for the grid stage of 256 frames - 2 % faster, at the price of a second implementation of the gradient.)
     const bool interior = tx0 >= 2 && ty0 >= 2 && tx0 + ME_TW + 2 <= w && ty0 + ME_TH + 2 <= h;
     const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float f1 = (float)(1.0f * scale_d), f0 = (float)(2.0f * scale_d);
-    if (interior) {
-        {   // all byte loads of a thread in flight before the first store (a plain loop makes one global round trip per byte)
-            constexpr int NPX = (ME_TH + 4) * (ME_TW + 4), NLD = (NPX + 255) / 256;
-            uint8_t v[NLD];
+    constexpr int PW = ME_TW + 8, PD = PW / 4;  // s_px: byte b of row r <-> pixel (tx0 - 4 + b, ty0 - 2 + r)
+    auto refl = [](int p, int len) { p = p < 0 ? -p : p >= len ? 2 * len - 2 - p : p; return min(max(p, 0), len - 1); };  // (far outside: clamped, unused)
+    if ((w & 3) == 0 && (((size_t)gray) & 3) == 0) {
+        // dword-aligned frame: 3 loads per thread, all in flight before the first store; rows are reflected per row, a dword that
+        // straddles the left or right image border (two per row of an edge tile) is assembled from reflected bytes
+        constexpr int NDW = (ME_TH + 4) * PD, NLD = (NDW + 255) / 256;
+        uint32_t v[NLD];
 #pragma unroll
-            for (int u = 0; u < NLD; u++) {
-                const int i = min(tid + u * 256, NPX - 1), r = i / (ME_TW + 4), c = i - r * (ME_TW + 4);
-                v[u] = gray[(size_t)(ty0 + r - 2) * w + tx0 + c - 2];
+        for (int u = 0; u < NLD; u++) {
+            const int i = min(tid + u * 256, NDW - 1), r = i / PD, c = i - r * PD;
+            const uint8_t* row = gray + (size_t)(interior ? ty0 + r - 2 : refl(ty0 + r - 2, h)) * w;
+            const int x0 = tx0 - 4 + 4 * c;
+            if (interior || (x0 >= 0 && x0 + 3 < w)) v[u] = *(const uint32_t*)(row + x0);
+            else {
+                v[u] = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) v[u] |= (uint32_t)row[refl(x0 + bb, w)] << (8 * bb);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++)
+            if (tid + u * 256 < NDW) ((uint32_t*)s_px)[tid + u * 256] = v[u];
+    } else {
+        // a frame that is not dword-aligned: bytes 2 .. ME_TW + 5 of every row, coordinates reflected once
+        constexpr int NB = ME_TW + 4, NPX = (ME_TH + 4) * NB, NLD = (NPX + 255) / 256;
+        uint8_t v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int i = min(tid + u * 256, NPX - 1), r = i / NB, c = i - r * NB;
+            v[u] = gray[(size_t)refl(ty0 + r - 2, h) * w + refl(tx0 + c - 2, w)];
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; u++) {
+            const int i = tid + u * 256, r = i / NB, c = i - r * NB;
+            if (i < NPX) s_px[r * PW + c + 2] = v[u];
+        }
+    }
+    __syncthreads();
+    {
+        // one task = 4 adjacent gradient positions out of 3 rows x 2 dwords, every byte converted once by v_cvt_f32_ubyteN (round 3's
+        // first form: 9 LDS byte reads + 9 conversions per gradient position).  (float)(a - b) of two bytes equals (float)a - (float)b
+        // exactly, so these are the oracle's float expressions in the oracle's order.
+        constexpr int NQ = (ME_TW + 2 + 3) / 4;  // quads of gradient positions per row (the last one is partly outside: not stored)
+        for (int i = tid; i < (ME_TH + 2) * NQ; i += 256) {
+            const int r = i / NQ, q = i - r * NQ;
+            // gradient column c = 4q + k (x = tx0 - 1 + c) reads pixel columns x - 1 .. x + 1 = bytes c + 2 .. c + 4: bytes 4q + 2 .. 4q + 7
+            float px[3][6];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const uint32_t* row = (const uint32_t*)(s_px + (r + j) * PW) + q;
+                const uint32_t d0 = row[0], d1 = row[1];
+                px[j][0] = (float)((d0 >> 16) & 0xFFu); px[j][1] = (float)(d0 >> 24);
+                px[j][2] = (float)(d1 & 0xFFu); px[j][3] = (float)((d1 >> 8) & 0xFFu); px[j][4] = (float)((d1 >> 16) & 0xFFu); px[j][5] = (float)(d1 >> 24);
             }
 #pragma unroll
-            for (int u = 0; u < NLD; u++)
-                if (tid + u * 256 < NPX) s_px[tid + u * 256] = v[u];
+            for (int k = 0; k < 4; k++) {
+                const int c = 4 * q + k;
+                if (c < ME_TW + 2) {
+                    const float Rm = px[0][k + 2] - px[0][k], R0 = px[1][k + 2] - px[1][k], Rp = px[2][k + 2] - px[2][k];
+                    const float t = Rm + Rp;
+                    const float uu = t * f1;
+                    const float vv = R0 * f0;
+                    s_dx[r * (ME_TW + 2) + c] = uu + vv;
+                    const float Cm = ((f1 * px[0][k]) + f0 * px[0][k + 1]) + f1 * px[0][k + 2];
+                    const float Cp = ((f1 * px[2][k]) + f0 * px[2][k + 1]) + f1 * px[2][k + 2];
+                    s_dy[r * (ME_TW + 2) + c] = Cp - Cm;
+                }
+            }
         }
+    }
+    if (!interior) {  // block-uniform: the ring a box sum of an in-image output reaches takes the gradients of its reflected positions
         __syncthreads();
         for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
             const int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
-            const uint8_t* rm = s_px + r * (ME_TW + 4) + c;        // rows y - 1, y, y + 1 of the gradient position, columns x - 1 .. x + 1
-            const uint8_t* r0 = rm + (ME_TW + 4);
-            const uint8_t* rp = r0 + (ME_TW + 4);
-            float Rm = (float)((int)rm[2] - (int)rm[0]), R0 = (float)((int)r0[2] - (int)r0[0]), Rp = (float)((int)rp[2] - (int)rp[0]);
-            float t = Rm + Rp;
-            float u = t * f1;
-            float v = R0 * f0;
-            s_dx[i] = u + v;
-            float Cm = ((f1 * (float)rm[0]) + f0 * (float)rm[1]) + f1 * (float)rm[2];
-            float Cp = ((f1 * (float)rp[0]) + f0 * (float)rp[1]) + f1 * (float)rp[2];
-            s_dy[i] = Cp - Cm;
-        }
-    } else {
-        for (int i = tid; i < (ME_TH + 2) * (ME_TW + 2); i += 256) {
-            int r = i / (ME_TW + 2), c = i - r * (ME_TW + 2);
-            int y = gf_reflect101(ty0 + r - 1, h), x = gf_reflect101(tx0 + c - 1, w);
-            const uint8_t* rm = gray + (size_t)gf_reflect101(y - 1, h) * w;
-            const uint8_t* r0 = gray + (size_t)y * w;
-            const uint8_t* rp = gray + (size_t)gf_reflect101(y + 1, h) * w;
-            int xm = gf_reflect101(x - 1, w), xp = gf_reflect101(x + 1, w);
-            float Rm = (float)((int)rm[xp] - (int)rm[xm]), R0 = (float)((int)r0[xp] - (int)r0[xm]),
-                  Rp = (float)((int)rp[xp] - (int)rp[xm]);
-            float t = Rm + Rp;
-            float u = t * f1;
-            float v = R0 * f0;
-            s_dx[i] = u + v;
-            float Cm = ((f1 * (float)rm[xm]) + f0 * (float)rm[x]) + f1 * (float)rm[xp];
-            float Cp = ((f1 * (float)rp[xm]) + f0 * (float)rp[x]) + f1 * (float)rp[xp];
-            s_dy[i] = Cp - Cm;
+            const int y = ty0 + r - 1, x = tx0 + c - 1;
+            if ((y == -1 || y == h || x == -1 || x == w) && y <= h && x <= w) {
+                const int src = (refl(y, h) - ty0 + 1) * (ME_TW + 2) + (refl(x, w) - tx0 + 1);  // an in-image position of this tile: never written here
+                s_dx[i] = s_dx[src];
+                s_dy[i] = s_dy[src];
+            }
         }
     }
     __syncthreads();
@@ -123,8 +161,9 @@ __global__ __launch_bounds__(256) void k_min_eigen(const uint8_t* __restrict__ g
 #define GF_MAXCORNERS 256
 
 #define GF_TILE_MAX 5248  // floats of the cell + 1-px ring held in LDS ((80 + 2) x (60 + 2) = 5084 at 640 x 480); larger cells read the map from global memory
-#define GF_TILE_KEYS 1024  // keys that may be filled while the tile is in use (typical: 50 - 120 local maxima per cell); the tile lies behind
-                          // them in the same array and becomes key space when a cell has more (29 KB in all: 5 workgroups per CU)
+#define GF_TILE_KEYS 384   // keys that may be filled while the tile is in use (typical: 50 - 120 local maxima per cell); the tile lies behind
+                          // them in the same array and becomes key space when a cell has more (24 KB in all, 6 workgroups per CU: 0.551 -> 0.535 ms
+                          // for the grid stage against 1024 keys / 29 KB / 5 workgroups; a cell with more lists its maxima again from global memory)
 
 // one workgroup per grid cell (blockIdx.y = frame of a batch)
 __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig, int w, int h, int cols, int cw, int ch,
