@@ -232,48 +232,58 @@ __global__ __launch_bounds__(256) void k_gftt_cell(const float* __restrict__ eig
     // 2. candidates: above threshold (THRESH_TOZERO) and equal to the 3x3 dilation of the thresholded map
     const int ya = max(y0, 1), yb = min(y1, h - 1), xa = max(x0, 1), xb = min(x1, w - 1);
     const int cw2 = xb - xa, n_in = cw2 > 0 && yb > ya ? cw2 * (yb - ya) : 0;
-    for (int pass = in_lds ? 0 : 1; pass < 2; pass++) {  // pass 0: out of the LDS tile; pass 1: from global memory (block-uniform)
-        const int key_cap = pass == 0 ? GF_TILE_KEYS : GF_CAP;
-        for (int i = tid; i < n_in; i += 256) {
-            int yy = ya + i / cw2, xx = xa + i % cw2;
-            float v, mx;
-            if (pass == 0) {
-                const float* p = s_tile + (yy - y0 + 1) * tw + (xx - x0 + 1);
-                v = p[0];
-                if (!(v > thr)) continue;
-                mx = v;
+    // (v > thr >= 0 and v == max over the 3x3 window of the THRESHOLDED map  <=>  v > thr and v >= its eight RAW neighbours: a
+    //  neighbour at or below the threshold counts as 0 < v either way)
+    if (in_lds && n_in > 0) {
+        // out of the LDS tile, one task = 4 adjacent positions of a row: 18 LDS reads, 12 + 4 three-way maxima (the first form read
+        // and thresholded nine values per position: 16 k of the workgroup's 41 k cycles)
+        const int nq = (cw2 + 3) >> 2, ntask = nq * (yb - ya);
+        const uint32_t inv_nq = 0xFFFFFFFFu / (uint32_t)nq + 1u;
+        for (int i = tid; i < ntask; i += 256) {
+            const int ry = nq > 1 ? (int)__umulhi((uint32_t)i, inv_nq) : i, q = i - ry * nq;
+            const int yy = ya + ry, xx0 = xa + 4 * q;
+            const float* p = s_tile + (yy - y0) * tw + (xx0 - x0);  // row yy - 1, column xx0 - 1 of the tile
+            const int cmax = tw - 1 - (xx0 - x0);                   // last readable column offset of this row (masked positions re-read it)
+            float hm[3][4], ctr[4];
 #pragma unroll
-                for (int j = -1; j <= 1; j++)
+            for (int j = 0; j < 3; j++) {
+                float a[6];
 #pragma unroll
-                    for (int k = -1; k <= 1; k++) {
-                        float q = p[j * tw + k];
-                        q = q > thr ? q : 0.f;
-                        mx = fmaxf(mx, q);
-                    }
-            } else {
-                const float* p = eig + (size_t)yy * w + xx;
-                v = p[0];
-                if (!(v > thr)) continue;
-                mx = v;
+                for (int k = 0; k < 6; k++) a[k] = p[j * tw + min(k, cmax)];
 #pragma unroll
-                for (int j = -1; j <= 1; j++)
-#pragma unroll
-                    for (int k = -1; k <= 1; k++) {
-                        float q = p[j * w + k];
-                        q = q > thr ? q : 0.f;
-                        mx = fmaxf(mx, q);
-                    }
+                for (int k = 0; k < 4; k++) hm[j][k] = fmaxf(fmaxf(a[k], a[k + 1]), a[k + 2]);
+                if (j == 1) { ctr[0] = a[1]; ctr[1] = a[2]; ctr[2] = a[3]; ctr[3] = a[4]; }
             }
-            if (v == mx) {
-                int slot = atomicAdd(&s_n, 1);
-                if (slot < key_cap) s_key[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float v = ctr[k], mx = fmaxf(fmaxf(hm[0][k], hm[1][k]), hm[2][k]);
+                if (xx0 + k < xb && v > thr && v == mx) {
+                    const int slot = atomicAdd(&s_n, 1);
+                    if (slot < GF_TILE_KEYS) s_key[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx0 + k);
+                }
             }
         }
         __syncthreads();
-        if (pass == 1 || s_n <= GF_TILE_KEYS) break;  // (block-uniform)
+    }
+    if (!in_lds || s_n > GF_TILE_KEYS) {  // (block-uniform) no tile, or more local maxima than fit beside it: list them from global memory
         __syncthreads();
-        if (tid == 0) s_n = 0;  // more local maxima than fit beside the tile: list them again without it
+        if (tid == 0) s_n = 0;
         __syncthreads();
+        for (int i = tid; i < n_in; i += 256) {
+            const int yy = ya + i / cw2, xx = xa + i % cw2;
+            const float* p = eig + (size_t)yy * w + xx;
+            const float v = p[0];
+            if (!(v > thr)) continue;
+            float mx = v;
+#pragma unroll
+            for (int j = -1; j <= 1; j++)
+#pragma unroll
+                for (int k = -1; k <= 1; k++) mx = fmaxf(mx, p[j * w + k]);
+            if (v == mx) {
+                const int slot = atomicAdd(&s_n, 1);
+                if (slot < GF_CAP) s_key[slot] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(yy * w + xx);
+            }
+        }
     }
     __syncthreads();
     const int n_all = s_n;  // every local maximum of the cell (the key array holds the first min(n_all, cap) of them)
