@@ -253,7 +253,9 @@ int mo_gather_map_points(mo_ctx*, const float* d_local, int rows_local, int rows
 /* Status of the mo_dev_* calls enqueued since the last mo_dev_status: the kernels never fault on overflow, they clamp and
  * raise a bit.  Host entry points keep their own flag words (checked inside each call): interleaving them with mo_dev_* calls
  * neither clears nor pollutes this status.  Synchronises the context stream, copies the flag word to flags[0] (flags may be NULL; [1..3] reserved, 0)
- * and clears it.  bit 0 (1): a level's internal keypoint slot overflowed (response ties at the quota cut);
+ * and clears it.  bit 0 (1): a level's internal keypoint slot overflowed (response ties at the quota cut: retainBest keeps every
+ * element that ties with the boundary; the slots grow eightfold when this status is read, so repeating the call succeeds after
+ * at most a few rounds - host entry points repeat by themselves);
  * bit 1 (2): a frame produced more keypoints than `cap` - its rows are truncated to cap while d_counts[frame] holds the
  * number it needed (so d_counts can EXCEED cap: clamp before indexing, or retry with cap >= max(d_counts));
  * bit 2 (4): not raised any more (rounds 2 - 3: more than 2048 local maxima in one grid cell; such cells are now processed in rounds).

@@ -378,3 +378,55 @@ def test_capacity_retry_and_huge_nfeatures(ctx, O):
     ek, ed = O.detect_and_compute(img, o)
     assert len(k) == len(ek) and np.array_equal(k["x"], ek["x"]) and np.array_equal(k["y"], ek["y"]) and np.array_equal(d, ed)
     O.lib().orc_set_variant(1, 0)
+
+
+def test_response_ties_beyond_the_level_slot_grow_the_slots(O):
+    """retainBest keeps EVERY element that ties with the quota boundary (KeyPointsFilter::retainBest: 'first among those equal to
+    the n-th'), so a level of a periodic pattern - an 8-px checkerboard: every corner has the same response - keeps far more than
+    its quota.  The per-level slots (4 x quota + 256) overflowed there (MO_ERR_CAPACITY until round 3; found by
+    tools/fuzz_parity.py); they now grow up to the level's candidate capacity: the host call repeats by itself, a device-resident
+    call raises status bit 0 once and succeeds when repeated."""
+    import ctypes as C
+    import torch
+    import vslam_amd as V
+    yy, xx = np.mgrid[0:264, 0:924]
+    img = (((yy // 8 + xx // 8) & 1) * 255).astype(np.uint8)
+    kw = dict(nfeatures=200, scale_factor=1.5, nlevels=8, fast_threshold=5, edge_threshold=25)
+    O.lib().orc_set_variant(1, 0)
+    ek, ed = O.detect_and_compute(img, O.params(**kw))
+    assert len(ek) > 2000   # ties: an order of magnitude more than nfeatures
+    c = V.Context(device=0, max_w=924, max_h=264, max_batch=2)
+    try:
+        prm = V.orb_params(select_order=V.ORDER_MSVC, **kw)
+        (kps, desc), = c.orb_detect_compute(img, prm)
+        assert all(np.array_equal(kps[f], ek[f]) for f in kps.dtype.names) and np.array_equal(desc, ed)
+    finally:
+        c.close()
+    # device-resident call on a fresh context: flag once, then the repeated call fits
+    c = V.Context(device=0, max_w=924, max_h=264, max_batch=2)
+    try:
+        dev = torch.device("cuda", 0)
+        c.set_stream(torch.cuda.current_stream().cuda_stream)
+        cap = len(ek) + 64
+        fr = torch.from_numpy(np.stack([img, img])).to(dev)
+        kp = torch.zeros((2, cap, 7), dtype=torch.float32, device=dev); ds = torch.zeros((2, cap, 32), dtype=torch.uint8, device=dev)
+        cn = torch.zeros(2, dtype=torch.int32, device=dev)
+        io = V.BatchIO()
+        io.d_gray = fr.data_ptr(); io.w = 924; io.h = 264; io.batch = 2; io.cap = cap
+        io.d_kps = kp.data_ptr(); io.d_desc = ds.data_ptr(); io.d_counts = cn.data_ptr()
+        c._check(c.lib.mo_dev_frontend_batch(c.h, C.byref(prm), C.byref(io)))
+        torch.cuda.synchronize()
+        assert c.dev_status() & 1
+        for _ in range(4):
+            c._check(c.lib.mo_dev_frontend_batch(c.h, C.byref(prm), C.byref(io)))
+            torch.cuda.synchronize()
+            if c.dev_status() == 0:
+                break
+        else:
+            raise AssertionError("the slots did not grow")
+        assert cn.cpu().tolist() == [len(ek), len(ek)]
+        got = kp[1, :len(ek)].cpu().numpy().view(np.uint8).reshape(-1).view(V.KP_DTYPE)
+        assert all(np.array_equal(got[f], ek[f]) for f in got.dtype.names) and np.array_equal(ds[1, :len(ek)].cpu().numpy(), ed)
+    finally:
+        c.close()
+        O.lib().orc_set_variant(1, 0)

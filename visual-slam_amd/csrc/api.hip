@@ -13,11 +13,13 @@
 // call between mo_dev_frontend_batch and mo_dev_status neither erases nor inherits the pending device-call bits.
 static inline int* host_flags(mo_ctx* c) { return c->d_flags + 4; }
 
+static bool grow_fin_slots(mo_ctx* c);
+
 static int check_flags(mo_ctx* c) {
     int f[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(f, host_flags(c), sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (f[0] & 1) return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)");
+    if (f[0] & 1) { c->tie_overflow = true; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
     if (f[0] & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
     return MO_OK;
 }
@@ -30,6 +32,7 @@ extern "C" int mo_dev_status(mo_ctx* c, int32_t flags[4]) {
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (flags) { flags[0] = f[0]; flags[1] = flags[2] = flags[3] = 0; }
+    if (f[0] & 1) grow_fin_slots(c);  // response ties overflowed a level's slot: the next call of the same shape rebuilds its plan with larger ones
     if (f[0] & 7) return mo_fail(c, MO_ERR_CAPACITY, "a capacity flag was raised by a mo_dev_* call (see mo_dev_status in vslam_amd.h)");
     return MO_OK;
 }
@@ -173,10 +176,34 @@ static int host_stage(mo_ctx* c, size_t bytes) {
     return MO_OK;
 }
 
+// true when a level's final-keypoint slot can still grow (then the plan is invalidated so that the next call rebuilds it larger).
+// retainBest keeps EVERY element that ties with the quota boundary, so a level of a periodic synthetic pattern can keep all its
+// candidates; the slots are sized for 4 quota + 256 and grow eightfold per overflow up to the level's candidate capacity.
+static bool grow_fin_slots(mo_ctx* c) {
+    if (!c->plan_valid) return false;
+    bool room = false;
+    for (int L = 0; L < c->plan.nlevels; L++) room |= c->plan.lv[L].fin_cap < c->plan.lv[L].cand_cap;
+    if (!room || c->fin_slack >= (1 << 24)) return false;
+    c->fin_slack *= 8;
+    return true;
+}
+
+static int detect_compute_once(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
+                               int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts);
+
 extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
                                      int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts) {
     if (!c) return MO_ERR_ARG;
     if (!kps || !counts) return mo_fail(c, MO_ERR_ARG, "kps/counts is NULL");
+    for (;;) {  // (at most 8 rounds: the slots reach the candidate capacity, where no overflow is possible)
+        c->tie_overflow = false;
+        const int rc = detect_compute_once(c, p, img, w, h, stride, ch, batch, kps, desc, cap, counts);
+        if (rc != MO_ERR_CAPACITY || !c->tie_overflow || !grow_fin_slots(c)) return rc;
+    }
+}
+
+static int detect_compute_once(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
+                               int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts) {
     HIPCHK(c, hipSetDevice(c->device));
     const uint8_t* d_gray = nullptr;
     int rc = mo_build_plan(c, p, w, h, batch);  // validates sizes before any staging
@@ -199,7 +226,7 @@ extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const ui
         HIPCHK(c, hipStreamSynchronize(c->stream));
         std::memcpy(counts, hs + o_cnt, (size_t)batch * sizeof(int));  // MO_ERR_CAPACITY: counts already holds the sizes a retry needs
         const int fl = ((const int*)hs)[0];
-        if (fl & 1) return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)");
+        if (fl & 1) { c->tie_overflow = true; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
         if (fl & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
         for (int f = 0; f < batch; f++) {
             const int n = std::min(counts[f], cap);

@@ -85,6 +85,8 @@ struct mo_ctx {
 
     // plan (rebuilt when w, h or the ORB parameters change)
     bool plan_valid = false;
+    int fin_slack = 1, plan_fin_slack = 1;  // per-level final-keypoint slots = min(candidates, (4 quota + 256) x fin_slack): grown when response ties overflow them
+    bool tie_overflow = false;              // the last host extraction raised flag bit 0
     mo_orb_params plan_params{};
     Plan plan{};
     ResizeTab rtab[MO_MAX_LEVELS];

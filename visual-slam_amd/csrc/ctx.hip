@@ -233,7 +233,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
     if (p->select_order != MO_ORDER_LIBSTDCXX && p->select_order != MO_ORDER_MSVC)
         return mo_fail(c, MO_ERR_ARG, "select_order must be MO_ORDER_LIBSTDCXX or MO_ORDER_MSVC");
 
-    bool same = c->plan_valid && params_equal(c->plan_params, *p) && c->plan.w == w && c->plan.h == h;
+    bool same = c->plan_valid && params_equal(c->plan_params, *p) && c->plan.w == w && c->plan.h == h && c->plan_fin_slack == c->fin_slack;
     if (same && batch <= c->batch_alloc) return MO_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_plan_buffers(c);
@@ -316,7 +316,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         v.cand_cap = v.nstrips * v.strip_cap;
         cand_off += v.cand_cap;
         v.fin_off = fin_off;
-        v.fin_cap = std::max(1, std::min(v.cand_cap, 4 * v.quota + 256));
+        v.fin_cap = (int)std::max<long long>(1, std::min<long long>(v.cand_cap, (4ll * v.quota + 256) * c->fin_slack));
         fin_off += v.fin_cap;
         v.scr_off = scr_off;
         // u64 records B + u32 records A + u16 partner positions + u64 ballots, in u64 units
@@ -379,5 +379,6 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
     c->batch_alloc = batch;
     c->plan_params = *p;
     c->plan_valid = true;
+    c->plan_fin_slack = c->fin_slack;
     return MO_OK;
 }
