@@ -430,3 +430,29 @@ def test_response_ties_beyond_the_level_slot_grow_the_slots(O):
     finally:
         c.close()
         O.lib().orc_set_variant(1, 0)
+
+
+def test_4k_frame(O):
+    """3840 x 2160 (263 FAST strips on level 0: above the 256 the selection kernel's prefix table held until round 3; level 0 alone
+    has several hundred thousand candidates): detect_and_compute, the grid detector and the matcher on the result, bit-exact."""
+    import vslam_amd as V
+    w, h = 3840, 2160
+    ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=1)
+    img = synthetic_frame(78, w, h)
+    try:
+        O.lib().orc_set_variant(0, 0)
+        p, o = _prm(V, O, 0, nfeatures=4000, fast_threshold=7)
+        (kps, desc), = ctx.orb_detect_compute(img, p)
+        ek, ed = O.detect_and_compute(img, o)
+        assert len(kps) == len(ek) == 4000
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(kps[f], ek[f]), f
+        assert np.array_equal(desc, ed)
+        exy = O.grid_good_features(img, 2000)
+        assert np.array_equal(ctx.grid_good_features(img, 2000), exy)
+        idx, dist, ps = ctx.match_knn2_ratio(desc, desc[::-1].copy(), 0.75)
+        eidx, edist = O.match_knn2(ed, ed[::-1].copy())
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    finally:
+        O.lib().orc_set_variant(1, 0)
+        ctx.close()
