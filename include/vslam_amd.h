@@ -258,6 +258,8 @@ int mo_gather_map_points(mo_ctx*, const float* d_local, int rows_local, int rows
  * at most a few rounds - host entry points repeat by themselves);
  * bit 1 (2): a frame produced more keypoints than `cap` - its rows are truncated to cap while d_counts[frame] holds the
  * number it needed (so d_counts can EXCEED cap: clamp before indexing, or retry with cap >= max(d_counts));
+ * bit 3 (8): a pair had more than 4096 correspondences (rows longer than 4096 are fine, a pair's ratio-test survivors or kept
+ * tracking matches beyond that are not): that pair gets no model (NaN pose, 0 points), the others are unaffected;
  * bit 2 (4): not raised any more (rounds 2 - 3: more than 2048 local maxima in one grid cell; such cells are now processed in rounds).
  * Returns MO_OK when no bit is set, MO_ERR_CAPACITY otherwise. */
 int mo_dev_status(mo_ctx*, int32_t flags[4]);

@@ -727,3 +727,94 @@ def test_grid_cells_with_more_local_maxima_than_one_sort_holds(name):
     finally:
         ctx.close()
         O.lib().orc_set_variant(1, 0)
+
+
+@pytest.mark.parametrize("mode", ["init", "track"])
+def test_batched_rows_longer_than_4096(mode):
+    """mo_dev_frontend_batch with 5000 features per frame (cap 5064) on 1280 x 720 frames: the two-view stage and the tracking filters
+    were refused for cap > 4096 until round 3 (MO_ERR_UNSUPPORTED for the whole call); what is limited is the number of
+    correspondences of ONE pair (4096: status bit 3, that pair gets no model), not the row length.  Keypoints equal the host call, the
+    pose of every pair equals the oracle on the same correspondences."""
+    import torch
+    import vslam_amd as V
+    from oracle import geom_oracle as G
+    from tests.helpers import parallax_frames
+    nb, cap, nfeat, w, h = 3, 5064, 5000, 1280, 720
+    frames = parallax_frames(nb, seed=61, w=w, h=h, bg_step=8, fg_step=16)
+    rng = np.random.Generator(np.random.PCG64(9))
+    frames = np.clip(frames.astype(np.float32) + rng.normal(0, 2.0, frames.shape), 0, 255).round().astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=nb)
+    try:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        prm = V.orb_params(nfeatures=nfeat)
+        io, b, _ = _batch_io(torch, V, dev, torch.from_numpy(frames).to(dev), nb, cap, 512)
+        K = np.array([[640.0, 0, 640.0], [0, 640.0, 360.0], [0, 0, 1.0]])
+        io.w, io.h = w, h
+        for i in range(9): io.K[i] = float(K.reshape(9)[i])
+        keep = []
+        if mode == "track":
+            sel = torch.zeros((nb - 1, cap, 2), dtype=torch.int32, device=dev); seln = torch.zeros(nb - 1, dtype=torch.int32, device=dev)
+            io.mode = V.MODE_TRACK; io.disp_frac = 0.02; io.thr_px = 1.0; io.d_sel_idx = sel.data_ptr(); io.d_sel_n = seln.data_ptr()
+            keep += [sel, seln]
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        torch.cuda.synchronize()
+        assert ctx.dev_status() == 0
+        cn = b["counts"].cpu().numpy()
+        assert (cn == nfeat).all()
+        host = V.Context(device=0, max_w=w, max_h=h, max_batch=1)
+        feats = [host.orb_detect_compute(frames[f], prm)[0] for f in range(nb)]
+        kp_np = b["kps"].cpu().numpy().view(np.uint8).reshape(nb, cap, 28)
+        for f in range(nb):
+            assert np.array_equal(kp_np[f, :nfeat].reshape(-1).view(V.KP_DTYPE), feats[f][0]), f
+            assert np.array_equal(b["desc"][f, :nfeat].cpu().numpy(), feats[f][1]), f
+        P = b["pose"].cpu().numpy(); NP = b["npts"].cpu().numpy()
+        for i in range(nb - 1):
+            idx, dist, ps = host.match_knn2_ratio(feats[i][1], feats[i + 1][1], 0.75)
+            assert np.array_equal(b["midx"][i, :nfeat].cpu().numpy(), idx) and np.array_equal(b["mpass"][i, :nfeat].cpu().numpy().astype(bool), ps)
+            if mode == "init":
+                assert ps.sum() > 1000
+                p1 = np.stack([feats[i][0]["x"], feats[i][0]["y"]], 1)[ps]
+                p2 = np.stack([feats[i + 1][0]["x"], feats[i + 1][0]["y"]], 1)[idx[ps, 0]]
+                o = G.init_two_view(p1, p2, K, thr_px=3.0, n_hyp=512, seed=4096, pair=i)
+                assert np.linalg.norm(P[i, :9].reshape(3, 3) - o["R"]) < 1e-4 and np.linalg.norm(P[i, 9:] - o["t"].ravel()) < 1e-4, i
+                assert abs(int(NP[i]) - o["n_good"]) <= 2
+            else:
+                n_sel = int(keep[1][i].item())
+                assert n_sel > 300 and np.isfinite(P[i]).all() and 0 < NP[i] <= n_sel
+                s = keep[0][i, :n_sel].cpu().numpy()
+                assert (s[:, 0] < nfeat).all() and (s[:, 0] >= 0).all() and s[:, 0].max() > 4096   # query indices beyond 12 bits survive the sort key
+                assert np.array_equal(s[:, 1], idx[s[:, 0], 0])
+        host.close()
+    finally:
+        ctx.close()
+
+
+def test_pair_with_more_than_4096_correspondences_gets_no_model():
+    """the limit the two-view stage does have: more than 4096 correspondences in ONE pair (here two identical frames with 5000
+    features: every query passes the ratio test) -> status bit 3, NaN pose and no points for that pair, the other pair unaffected."""
+    import torch
+    import vslam_amd as V
+    from tests.helpers import parallax_frames
+    nb, cap, nfeat, w, h = 3, 5064, 5000, 1280, 720
+    frames = parallax_frames(nb, seed=62, w=w, h=h, bg_step=8, fg_step=16).copy()
+    frames[2] = frames[1]
+    dev = torch.device("cuda", 0)
+    ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=nb)
+    try:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        prm = V.orb_params(nfeatures=nfeat)
+        io, b, _ = _batch_io(torch, V, dev, torch.from_numpy(frames).to(dev), nb, cap, 512)
+        io.w, io.h = w, h
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
+        torch.cuda.synchronize()
+        assert ctx.dev_status() == 8
+        assert int(b["mpass"][1].sum().item()) == nfeat           # the identical pair: every query passes
+        P = b["pose"].cpu().numpy(); NP = b["npts"].cpu().numpy()
+        assert np.isfinite(P[0]).all() and NP[0] > 100 and np.isnan(P[1]).all() and NP[1] == 0
+        assert np.isnan(b["pts"][1].cpu().numpy()).all()
+        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))   # (the status word was cleared by the read)
+        torch.cuda.synchronize()
+        assert ctx.dev_status() == 8
+    finally:
+        ctx.close()

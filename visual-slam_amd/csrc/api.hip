@@ -33,7 +33,7 @@ extern "C" int mo_dev_status(mo_ctx* c, int32_t flags[4]) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (flags) { flags[0] = f[0]; flags[1] = flags[2] = flags[3] = 0; }
     if (f[0] & 1) grow_fin_slots(c);  // response ties overflowed a level's slot: the next call of the same shape rebuilds its plan with larger ones
-    if (f[0] & 7) return mo_fail(c, MO_ERR_CAPACITY, "a capacity flag was raised by a mo_dev_* call (see mo_dev_status in vslam_amd.h)");
+    if (f[0] & 15) return mo_fail(c, MO_ERR_CAPACITY, "a capacity flag was raised by a mo_dev_* call (see mo_dev_status in vslam_amd.h)");
     return MO_OK;
 }
 

@@ -213,7 +213,9 @@ struct TwoViewArgs {
     uint8_t* d_inlier; // [pairs][cap] pose mask
     uint8_t* d_ransac; // [pairs][cap] RANSAC (Sampson) mask or null
     int32_t* d_n_points; // [pairs]
+    int* flags;          // capacity flag word (bit 3: a pair with more than TV_MAX_M correspondences gets no model); set by twoview_launch
 };
+#define TV_MAX_M 4096     // correspondences of one pair the two-view stage takes (sampler arithmetic, per-thread consensus bits)
 int twoview_launch(mo_ctx* c, const TwoViewArgs& a);
 // undistort_kernels.hip
 int undistort_launch(mo_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int ch, int batch, const double K[9],

@@ -7,8 +7,8 @@
 // cv2.findEssentialMat(..., RANSAC, 0.999, 1.0) and cv2.recoverPose (tracker.py:242-249): k_track_select writes that list
 // and the two-view kernels (twoview_kernels.hip) consume it instead of the ratio-test flags.
 //
-// One workgroup per frame pair.  Distances are integers 0..256 and a pair has at most 4096 matches, so the sort key
-// (distance << 12 | query index) is unique and the stable order is its plain order: every survivor counts the smaller keys
+// One workgroup per frame pair.  Distances are integers 0..256 and a pair has at most 8192 matches, so the sort key
+// (distance << 16 | query index) is unique and the stable order is its plain order: every survivor counts the smaller keys
 // (LDS broadcast reads; a few hundred survivors per pair) and scatters itself to that rank.  np.median of the sorted list is
 // (d[(n-1)/2] + d[n/2]) / 2, so "distance < 2 * median" is the integer test  distance < d[(n-1)/2] + d[n/2]  and, the
 // list being sorted, the kept matches are a prefix.
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
         __syncthreads();
         int off = s_base;
         for (int k = 0; k < wv; k++) off += s_w[k];
-        if (ok) s_key[off + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)d << 12) | (uint32_t)i;
+        if (ok) s_key[off + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)d << 16) | (uint32_t)i;
         __syncthreads();
         if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
     // 3. 2 * median = d[(n-1)/2] + d[n/2]; kept = the prefix with distance below it
     int n_keep = 0;
     if (n > 0) {
-        const int thr = (int)(s_sorted[(n - 1) >> 1] >> 12) + (int)(s_sorted[n >> 1] >> 12);
+        const int thr = (int)(s_sorted[(n - 1) >> 1] >> 16) + (int)(s_sorted[n >> 1] >> 16);
         int cnt = 0;
-        for (int e = tid; e < n; e += TS_BLOCK) cnt += (int)(s_sorted[e] >> 12) < thr ? 1 : 0;
+        for (int e = tid; e < n; e += TS_BLOCK) cnt += (int)(s_sorted[e] >> 16) < thr ? 1 : 0;
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
         if (lane == 0) s_w[wv] = cnt;
         __syncthreads();
@@ -81,10 +81,10 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
     int32_t* out = sel + (size_t)pair * cap * 2;
     for (int e = tid; e < n_keep; e += TS_BLOCK) {
         const uint32_t key = s_sorted[e];
-        const int i = key & 0xFFF;
+        const int i = key & 0xFFFF;
         out[2 * e] = i;
         out[2 * e + 1] = idx[2 * i];
-        if (sel_dist) sel_dist[(size_t)pair * cap + e] = (int)(key >> 12);
+        if (sel_dist) sel_dist[(size_t)pair * cap + e] = (int)(key >> 16);
     }
     if (tid == 0) sel_n[pair] = n_keep;
 }
@@ -93,7 +93,7 @@ int track_select_launch(mo_ctx* c, const mo_keypoint* d_kps, const int32_t* d_co
                         const int32_t* d_midx, const int32_t* d_mdist, const uint8_t* d_mpass, int cap, int n_pairs, int w, int h,
                         double disp_frac, int32_t* d_sel, int32_t* d_sel_dist, int32_t* d_sel_n) {
     if (n_pairs <= 0) return MO_OK;
-    if (cap > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "tracking filters support at most 4096 keypoints per frame");
+    if (cap > 8192) return mo_fail(c, MO_ERR_UNSUPPORTED, "tracking filters support at most 8192 keypoints per frame (two key arrays in 64 KB of LDS)");
     const double max_disp = ((double)(w + h) / 2.0) * disp_frac;  // matcher.py:128 ((width + height) / 2.0) * threshold_percent
     hipLaunchKernelGGL(k_track_select, dim3(n_pairs), dim3(TS_BLOCK), (size_t)cap * 2 * sizeof(uint32_t), c->stream, d_kps, d_counts,
                        d_qf, d_tf, d_midx, d_mdist, d_mpass, cap, max_disp, d_sel, d_sel_dist, d_sel_n);

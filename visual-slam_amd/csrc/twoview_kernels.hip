@@ -547,7 +547,8 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     const mo_keypoint* k1 = a.d_kps + (size_t)qfr * a.cap;
     const mo_keypoint* k2 = a.d_kps + (size_t)tfr * a.cap;
     if (a.d_sel) {  // tracking mode: the filtered match list in the reference's order (track_kernels.hip)
-        const int m = min(a.d_sel_n[pair], a.cap);
+        int m = min(a.d_sel_n[pair], a.cap);
+        if (m > TV_MAX_M) { if (tid == 0) atomicOr(&a.flags[0], 8); m = 0; }  // (block-uniform) no model for this pair, status bit 3
         const int32_t* sl = a.d_sel + (size_t)pair * a.cap * 2;
         for (int o = tid; o < m; o += TV_BLOCK) {
             const int i = sl[2 * o], j = sl[2 * o + 1];
@@ -590,9 +591,11 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
-    if (tid == 0) w.m[pair] = s_base;
-    if (a.model) tv_hartley(a, w, pair, s_base);
-    tv_f32_copy(a, w, pair, s_base);
+    int m = s_base;
+    if (m > TV_MAX_M) { if (tid == 0) atomicOr(&a.flags[0], 8); m = 0; }  // (block-uniform) no model for this pair, status bit 3
+    if (tid == 0) w.m[pair] = m;
+    if (a.model) tv_hartley(a, w, pair, m);
+    tv_f32_copy(a, w, pair, m);
 }
 
 // ---------------------------------------------------------------- hypotheses ----------------------
@@ -1185,9 +1188,13 @@ int triangulate_launch(mo_ctx* c, const double* P1, const double* P2, const floa
     return MO_OK;
 }
 
-int twoview_launch(mo_ctx* c, const TwoViewArgs& a) {
-    if (a.n_pairs <= 0) return MO_OK;
-    if (a.cap > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "two-view stage supports at most 4096 correspondences per pair");
+int twoview_launch(mo_ctx* c, const TwoViewArgs& a_in) {
+    if (a_in.n_pairs <= 0) return MO_OK;
+    // (rows may be longer than TV_MAX_M - a batch extracted with 6000 features per frame: what counts is the number of
+    //  correspondences of a pair, checked on the device; explicit point lists are checked by their entry points)
+    if (a_in.d_p1 && a_in.m_fixed > TV_MAX_M) return mo_fail(c, MO_ERR_UNSUPPORTED, "two-view stage supports at most 4096 correspondences per pair");
+    TwoViewArgs a = a_in;
+    a.flags = c->flags_cur ? c->flags_cur : c->d_flags;
     if (!a.d_E_in && (a.n_hyp < 1 || a.n_hyp > (1 << 20))) return mo_fail(c, MO_ERR_ARG, "n_hyp out of range");
     size_t need = twoview_workspace_bytes(a.n_pairs, a.cap, a.n_hyp);
     int rc = mo_reserve(c, c->d_tv, c->tv_bytes, need);
