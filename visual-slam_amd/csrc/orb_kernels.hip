@@ -813,7 +813,7 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, i
 #define SEL_BUF_BYTES (46 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): holds the ~9000 candidates a
                                    // dense 640x480 level 0 produces (5.125 B each with the replay's side arrays; SURVEY 8d texture: 6600 -
                                    // 7000); 3 workgroups per CU with the 3.4 KB of Harris windows and the replay scratch
-#define SEL_MAXSTRIPS 1024
+#define SEL_MAXSTRIPS 2047  // strips of one level (8K frames: 540); their prefix table lies behind the record window in dynamic LDS
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
 __device__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
@@ -964,8 +964,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
                                                         uint64_t* __restrict__ scratch, size_t scratch_stride,
                                                         FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags,
                                                         int level0, int buf_bytes, int* __restrict__ desc_todo) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less)
-    __shared__ int s_pref[SEL_MAXSTRIPS + 1];
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less) + the strip prefix table
+    int* const s_pref = (int*)(s_buf + buf_bytes);  // [max strips of a level + 1] (sized by the launch: 1 KB at 640 x 480; a static 4 KB
+                                                    // table for 4K frames cost every launch a workgroup per CU: 0.218 -> 0.303 ms)
     __shared__ replay::WgScratch s_ws;
     const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;  // dispatch order: all frames of the finest level first
     if (desc_todo && frame == 0 && blockIdx.y == 0 && tid == 0) desc_todo[0] = 0;  // k_describe_tiles' list of left-over tiles (this call's)
@@ -1045,8 +1046,12 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo,
     if (level_lo >= level_hi) return MO_OK;
     for (int L = 0; L < P.nlevels; L++)
         if (P.lv[L].nstrips > SEL_MAXSTRIPS) return mo_fail(c, MO_ERR_UNSUPPORTED, "too many strips per level");
+    int max_strips = 1;
+    for (int L = 0; L < P.nlevels; L++) max_strips = std::max(max_strips, P.lv[L].nstrips);
+    const size_t pref_bytes = (((size_t)max_strips + 1) * sizeof(int) + 15) & ~(size_t)15;
     if (!(c->lds_attr_done & 16u)) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_BUF_BYTES));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SEL_BUF_BYTES + ((((size_t)SEL_MAXSTRIPS + 1) * sizeof(int) + 15) & ~(size_t)15)));
         c->lds_attr_done |= 16u;
     }
     // One launch, every workgroup with the full LDS record window (4 resident per CU), levels in dispatch order from fine to
@@ -1056,7 +1061,7 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo,
     // alternatives on MI355X: a second launch for the coarse levels with a smaller window (8 - 24 KB, more workgroups per CU):
     // 0.23 - 0.25 ms against 0.20 ms; selecting the finest level on the auxiliary stream beside FAST of the others: no gain
     // (the coarse levels alone take 0.19 ms: the kernel is bound by the sum of the replays, not by the finest level).
-    hipLaunchKernelGGL(k_select, dim3(batch, level_hi - level_lo), dim3(SEL_THREADS), SEL_BUF_BYTES, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+    hipLaunchKernelGGL(k_select, dim3(batch, level_hi - level_lo), dim3(SEL_THREADS), SEL_BUF_BYTES + pref_bytes, c->stream, P, d_gray, c->d_pyr, c->d_cand,
                        c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES, c->d_dtodo);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
