@@ -8,7 +8,7 @@ tmp=$(mktemp -d /tmp/variant.XXXX)
 mkdir -p $tmp/visual-slam_amd $tmp/include
 cp -r $root/visual-slam_amd/csrc $tmp/visual-slam_amd/ && rm -rf $tmp/visual-slam_amd/csrc/_obj
 cp $root/include/vslam_amd.h $tmp/include/
-make -C $tmp/visual-slam_amd/csrc -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wno-unused-value -Wno-unused-result $defs" > /dev/null
+make -C $tmp/visual-slam_amd/csrc -j8 EXTRA="$defs" > /dev/null
 mkdir -p $root/visual-slam_amd/variants
 cp $tmp/visual-slam_amd/libvslam_amd.so $root/visual-slam_amd/variants/lib$name.so
 rm -rf $tmp

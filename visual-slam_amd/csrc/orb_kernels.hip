@@ -810,7 +810,10 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, i
 }
 
 // ------------------------------------------------------------------ select --------------------------
-#define SEL_BUF_BYTES (46 * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): holds the ~9000 candidates a
+#ifndef SEL_BUF_KB
+#define SEL_BUF_KB 46
+#endif
+#define SEL_BUF_BYTES (SEL_BUF_KB * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): holds the ~9000 candidates a
                                    // dense 640x480 level 0 produces (5.125 B each with the replay's side arrays; SURVEY 8d texture: 6600 -
                                    // 7000); 3 workgroups per CU with the 3.4 KB of Harris windows and the replay scratch
 #define SEL_MAXSTRIPS 2047  // strips of one level (8K frames: 540); their prefix table lies behind the record window in dynamic LDS
