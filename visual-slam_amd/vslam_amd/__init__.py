@@ -248,8 +248,8 @@ class Context:
         b, h, w = a.shape[0], a.shape[1], a.shape[2]
         cap = int(cap or (prm.nfeatures + 1024))
         while True:
-            kps = np.zeros((b, cap), KP_DTYPE)
-            desc = np.zeros((b, cap, 32), np.uint8) if want_desc else None
+            kps = np.empty((b, cap), KP_DTYPE)   # (only the rows the library fills are handed out)
+            desc = np.empty((b, cap, 32), np.uint8) if want_desc else None
             counts = np.zeros(b, np.int32)
             rc = self.lib.mo_orb_detect_compute(self.h, C.byref(prm), _ptr(a), w, h, w * ch, ch, b, _ptr(kps),
                                                 _ptr(desc), cap, _ptr(counts))
@@ -261,7 +261,8 @@ class Context:
         out = []
         for f in range(b):
             n = int(counts[f])
-            out.append((kps[f, :n].copy(), desc[f, :n].copy() if want_desc and n else None))
+            # views of this call's own buffers (fresh per call, nobody else holds them): no second copy of 120 KB per frame
+            out.append((kps[f, :n], desc[f, :n] if want_desc and n else None))
         return out
 
     def orb_compute(self, image, prm, kps_in):
