@@ -32,3 +32,10 @@ def test_random_configurations_of_the_batched_call_equal_the_host_api(capsys):
     out = capsys.readouterr().out
     assert rc == 0 and "MISMATCH" not in out and "refused" not in out, out[-2000:]
     assert " 0 with a mismatch" in out
+
+
+def test_random_configurations_of_the_geometry_calls_equal_the_oracle(capsys):
+    rc = _tool("fuzz_geometry").main(["--n", "80", "--seed", "13", "--budget-s", "120"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "MISMATCH" not in out, out[-2000:]
+    assert " 0 with a mismatch" in out
