@@ -15,6 +15,7 @@ import numpy as np
 sys.path.insert(0, "visual-slam_amd"); sys.path.insert(0, ".")
 import torch                               # noqa: E402
 import vslam_amd as V                      # noqa: E402
+from oracle import geom_oracle as G        # noqa: E402
 from tests.helpers import synthetic_frame  # noqa: E402
 
 
@@ -150,6 +151,14 @@ def main(argv=None):
                 if not (np.array_equal(MI[j, :nq], idx) and np.array_equal(MD[j, :nq], dist) and np.array_equal(MP[j, :nq], ps)) or MP[j, nq:].any():
                     ok = False
                     print("MISMATCH pair %d (%d, %d): match lists" % (j, qa, ta), cfg, flush=True)
+                if mode == V.MODE_TRACK:   # the kept list of the two tracking filters, in the reference's order: integer work, exact
+                    eq, et, _ = G.track_select(np.stack([feats[qa][0]["x"], feats[qa][0]["y"]], 1), np.stack([feats[ta][0]["x"], feats[ta][0]["y"]], 1),
+                                               idx, dist, ps, w, h, 0.02)
+                    ns = int(keep[-1][j].item())
+                    got = keep[-2][j, :ns].cpu().numpy()
+                    if ns != len(eq) or not np.array_equal(got[:, 0], eq) or not np.array_equal(got[:, 1], et):
+                        ok = False
+                        print("MISMATCH pair %d: tracking filter list %d vs %d" % (j, ns, len(eq)), cfg, flush=True)
                 if mode != V.MODE_KEYFRAME:
                     R = P[j, :9].reshape(3, 3)
                     sound = np.isnan(P[j]).all() or (np.allclose(R @ R.T, np.eye(3), atol=1e-8) and abs(np.linalg.det(R) - 1) < 1e-8
