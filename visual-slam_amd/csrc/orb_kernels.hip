@@ -657,9 +657,16 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
             const uint8_t* w = &s_tile[r * TW + lead + min(x, SW - 1)];
             const int v = w[3 * TW + 3];
             const int d0 = sub16(v, w[6 * TW + 3]), d4 = sub16(v, w[3 * TW + 6]), d8 = sub16(v, w[3]), d12 = sub16(v, w[3 * TW]);
+#ifdef FAST_COMPASS_ANY2
             const int mn_a = min16(d0, d4), mx_a = max16(d0, d4), mn_b = min16(d8, d12), mx_b = max16(d8, d12);
             const int second_hi = max16(max16(min16(mx_a, mx_b), mn_a), mn_b);
             const int second_lo = min16(min16(max16(mn_a, mn_b), mx_a), mx_b);
+#else
+            // two ADJACENT compass pixels (a 9-arc holds two or three consecutive multiples of 4): 14 instead of 10 min / max, but 0.62
+            // instead of 0.67 survivors per pixel on the SURVEY-8d texture
+            const int second_hi = max16(max16(min16(d0, d4), min16(d4, d8)), max16(min16(d8, d12), min16(d12, d0)));
+            const int second_lo = min16(min16(max16(d0, d4), max16(d4, d8)), min16(max16(d8, d12), max16(d12, d0)));
+#endif
             const unsigned long long md = ballot_gt16(second_hi, tv) & valid;   // centre above >= 2 compass pixels by more than t
             const unsigned long long mb = ballot_gt16(ntv, second_lo) & valid;  // centre below >= 2 compass pixels by more than t
             const uint32_t e = (uint32_t)((r << xbits) | x);
