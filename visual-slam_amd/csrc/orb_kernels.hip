@@ -583,8 +583,8 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
     __syncthreads();
 
     // ---- 2. scores.
-    // 2a (every pixel, 5 LDS reads): a 9-arc of the 16-circle always contains >= 2 of the 4 compass pixels, so a pixel
-    //     with fewer than 2 compass differences above t AND fewer than 2 below -t cannot be a corner: score 0.  Which of
+    // 2a (every pixel, 5 LDS reads): a 9-arc of the 16-circle always contains two ADJACENT compass pixels (positions 0, 4, 8, 12),
+    //     so a pixel without two adjacent compass differences above t AND without two below -t cannot be a corner: score 0.  Which of
     //     the two holds also fixes the ONLY polarity the pixel can be a corner with (two 9-arcs of a 16-circle overlap, so a
     //     pixel cannot have both a darker and a brighter arc): survivors are appended to a per-wavefront LDS stack with that
     //     polarity (ballot + prefix popcount); the rare pixel that passes both tests is pushed once per polarity.
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(NT) void k_fast(Plan P, const uint32_t* __restrict_
         const int tv = t, ntv = -t;
         // branch-free: lanes past the last scored column read a clamped (valid) address and are masked out of the result;
         // the window base sits 3 rows and 3 columns before the pixel so that all five reads use non-negative immediates.
-        // second largest of the 4 compass differences > t <=> >= 2 of them above t; second smallest < -t <=> >= 2 below -t
+        // largest of the four adjacent-pair minima > t <=> two adjacent differences above t; smallest of the pair maxima < -t likewise
         auto chunk = [&](int r, int j) {
             const int x = (j << 6) + lane;
             const int rem = SW - (j << 6);  // scored columns left from this chunk on (wave-uniform, >= 1)
