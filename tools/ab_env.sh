@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/ab_env.sh VAR val1 val2 ... -- interleaved bench.py runs on one box with VAR set to each value in turn (3 rounds):
-# ms_per_step and the per-stage spans of every run.  Usage on the GPU box: bash tools/ab_env.sh VSLAM_AMD_DESCRIBE tiles patch
+# ms_per_step and the per-stage spans of every run.  Usage on the GPU box: bash tools/ab_env.sh VSLAM_AMD_MATCHER lds mfma
 VAR=$1; shift
 for round in 1 2 3; do
   for v in "$@"; do

@@ -107,9 +107,7 @@ struct mo_ctx {
     int tile_cum[2][MO_MAX_LEVELS + 1] = {};               // tiles of levels < L (the tables are level-major: a prefix blurs the first levels)
     int tile_margin = 0;
     uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
-    int* d_lv_tab = nullptr;       // k_describe: per-level geometry table (built with the plan)
     uint32_t* d_dtile_tab = nullptr; int n_dtiles = 0, dtile_icw_off = 0;  // k_describe_tiles: tile -> level | column << 8 | row << 20, then the centroid weights
-    bool describe_patch = false;   // VSLAM_AMD_DESCRIBE=patch: the per-keypoint window kernel of rounds 1 - 2 (A/B timing)
     int* d_dtodo = nullptr; size_t dtodo_bytes = 0;  // k_describe_tiles -> k_describe_tiles_rare: [0] count, then frame * tiles + tile
     int* d_flags = nullptr;        // [8] error flags raised by kernels: words 0..3 belong to the mo_dev_* calls (they accumulate until
                                    // mo_dev_status), words 4..7 to the host entry points (cleared and checked inside each call)

@@ -65,7 +65,6 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
             c->serial_blur = true;
     }
     if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
-    if (const char* e = getenv("VSLAM_AMD_DESCRIBE")) c->describe_patch = e[0] == 'p';
     if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
     if (const char* e = getenv("VSLAM_AMD_POISON")) c->poison = atoi(e) & 255;
     if (const char* e = getenv("VSLAM_AMD_STRIP_ROWS")) c->strip_rows = std::min(std::max(atoi(e), 2), 16);
@@ -96,8 +95,8 @@ static void free_plan_buffers(mo_ctx* c) {
         if (t.xpk) hipFree(t.xpk);
         t = ResizeTab();
     }
-    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab[0], c->d_tile_tab[1], c->d_strip_tab, c->d_lv_tab, c->d_dtile_tab};
-    c->d_lv_tab = nullptr; c->d_dtile_tab = nullptr; c->n_dtiles = 0;
+    void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab[0], c->d_tile_tab[1], c->d_strip_tab, c->d_dtile_tab};
+    c->d_dtile_tab = nullptr; c->n_dtiles = 0;
     for (void* b : bufs) if (b) hipFree(b);
     c->d_tile_tab[0] = c->d_tile_tab[1] = nullptr; c->d_strip_tab = nullptr; c->n_strip_tab = 0;
     c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_strip_cnt = nullptr; c->d_scratch = nullptr;

@@ -1164,88 +1164,7 @@ __device__ __forceinline__ void rbrief_wave(const uint8_t* blur, int bpitch, con
     if ((lane & 1) == 0) desc[lane >> 1] = (uint8_t)(nib | (hi << 4));
 }
 
-// per-level table of k_describe (device copy built with the plan): the LevelInfo fields it needs, as ints
-#define DLV_N 8
-#define DLV_PITCH 0
-#define DLV_OFF 1
-#define DLV_BPITCH 2
-#define DLV_BOFF 3
-#define DLV_FIN_OFF 4
-#define DLV_SCALE 5
-
-#define DP_RAW_PITCH 36   // 31 columns + <= 3 alignment lead-in, 9 dwords
-#define DP_BLR_PITCH 44   // 39 columns + <= 3 alignment lead-in, 11 dwords
-#define DP_PATCH_BYTES (39 * DP_BLR_PITCH)  // one LDS patch per keypoint: first the raw 31x31 window, then the blurred 39x39 one
-
 #define DG 16                 // lanes per keypoint (a quarter of a wavefront)
-#define DK_PER_WG (256 / DG)  // keypoints per 256-thread workgroup
-
-// A ROWS x NDW-dword window whose first column is x0a (a multiple of 4), spread over the DG = 16 lanes of a keypoint group
-// so that addresses advance by a constant per step (the kernel is VALU-bound: address arithmetic is what this saves):
-//   part A, dword columns 0..7 : lane gl takes column gl & 7 of row 2 s + (gl >> 3) in step s       (two rows per step)
-//   part B, columns 8..NDW-1   : NDW = 9 : lane gl takes column 8 of row 16 s + gl
-//                                NDW = 11: lane gl takes column 8 + min(gl & 3, 2) of row 4 s + (gl >> 2)
-// patch_load only issues the global loads (the registers are consumed later, so the loads of both patches are in flight
-// together); patch_store puts them into LDS, where the per-step stride is an immediate offset.
-template <int ROWS, int NDW> struct PatchMap {
-    static constexpr int SA = (ROWS + 1) / 2;
-    static constexpr int EC = NDW - 8;            // extra dword columns: 1 or 3
-    static constexpr int RB = EC == 1 ? 16 : 4;   // rows per step of part B
-    static constexpr int SB = (ROWS + RB - 1) / RB;
-    static constexpr int N = SA + SB;
-    static_assert(EC == 1 || EC == 3, "window of 9 or 11 dwords");
-};
-
-template <int ROWS, int NDW, int N>
-__device__ __forceinline__ void patch_load(const uint8_t* img, int pitch, int x0a, int y0, int gl, bool aligned, uint32_t (&reg)[N]) {
-    typedef PatchMap<ROWS, NDW> PM;
-    static_assert(N == PM::N && DG == 16, "register tile shape");
-    const int ra = gl >> 3, ca = gl & 7;
-    const int rb = PM::EC == 1 ? gl : gl >> 2, cb = PM::EC == 1 ? 8 : 8 + min(gl & 3, PM::EC - 1);
-    if (aligned) {  // the caller keeps x0a + 4 NDW <= pitch: every dword of the window lies inside its row
-        const uint8_t* base = img + (size_t)y0 * pitch + x0a;
-        int off = ra * pitch + 4 * ca;
-#pragma unroll
-        for (int st = 0; st < PM::SA; st++) {  // only the last step can run past the window: it re-reads the last row
-            reg[st] = *(const uint32_t*)(base + (st == PM::SA - 1 ? min(2 * st + ra, ROWS - 1) * pitch + 4 * ca : off));
-            off += 2 * pitch;
-        }
-        off = rb * pitch + 4 * cb;
-#pragma unroll
-        for (int st = 0; st < PM::SB; st++) {
-            reg[PM::SA + st] = *(const uint32_t*)(base + (st == PM::SB - 1 ? min(PM::RB * st + rb, ROWS - 1) * pitch + 4 * cb : off));
-            off += PM::RB * pitch;
-        }
-    } else {
-#pragma unroll 1
-        for (int k = 0; k < N; k++) {
-            const int r = k < PM::SA ? 2 * k + ra : PM::RB * (k - PM::SA) + rb, c = k < PM::SA ? ca : cb;
-            uint32_t v = 0;
-            if (r < ROWS) {
-                const uint8_t* p = img + (size_t)(y0 + r) * pitch + x0a + 4 * c;
-                for (int bq = 0; bq < 4; bq++)
-                    if (x0a + 4 * c + bq < pitch) v |= (uint32_t)p[bq] << (8 * bq);
-            }
-            reg[k] = v;
-        }
-    }
-}
-
-template <int ROWS, int NDW, int N>
-__device__ __forceinline__ void patch_store(uint8_t* dst, int dpitch, int gl, const uint32_t (&reg)[N]) {
-    typedef PatchMap<ROWS, NDW> PM;
-    const int ra = gl >> 3, ca = gl & 7;
-    const int rb = PM::EC == 1 ? gl : gl >> 2, cb = PM::EC == 1 ? 8 : 8 + min(gl & 3, PM::EC - 1);
-    uint8_t* da = dst + ra * dpitch + 4 * ca;
-#pragma unroll
-    for (int st = 0; st < PM::SA; st++)
-        if (st < PM::SA - 1 || 2 * st + ra < ROWS) *(uint32_t*)(da + st * 2 * dpitch) = reg[st];
-    uint8_t* db = dst + rb * dpitch + 4 * cb;
-    const bool own = PM::EC == 1 || (gl & 3) < PM::EC;  // NDW = 11: the fourth lane of a row only duplicated a load
-#pragma unroll
-    for (int st = 0; st < PM::SB; st++)
-        if (own && (st < PM::SB - 1 || PM::RB * st + rb < ROWS)) *(uint32_t*)(db + st * PM::RB * dpitch) = reg[PM::SA + st];
-}
 
 __device__ __forceinline__ int group_sum(int v) {  // sum over the DG lanes of a keypoint group
 #pragma unroll
@@ -1253,31 +1172,7 @@ __device__ __forceinline__ int group_sum(int v) {  // sum over the DG lanes of a
     return v;
 }
 
-// 256 rotated binary tests from an LDS patch, 16 per lane of a 16-lane group: lane gl produces descriptor bytes 2gl, 2gl+1
-__device__ __forceinline__ uint16_t rbrief_u16(const uint8_t* patch, int ppitch, int cx, int cy, float angle_deg, int gl) {
-    float angle = angle_deg;
-    angle *= (float)(3.14159265358979323846 / 180.f);
-    double sd, cd;
-    sincos((double)angle, &sd, &cd);  // f64 then rounded to f32, as cv2's (float)cos(angle) / (float)sin(angle)
-    const float a = (float)cd, b = (float)sd;
-    const int cxm = cx - 0x4B400000, cym = cy - 0x4B400000;
-    unsigned val = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int8_t* pt = &c_pattern[(gl * 16 + k) * 4];
-        float fx0 = (float)pt[0], fy0 = (float)pt[1], fx1 = (float)pt[2], fy1 = (float)pt[3];
-        // cvRound (round half to even) of |v| < 2^22 as the low bits of v + 1.5 * 2^23: one full-rate v_add_f32 instead of
-        // v_rndne_f32 + v_cvt_i32_f32 (both half rate); the bias 0x4B400000 is folded into cxm / cym
-        const int jx0 = __float_as_int((fx0 * a - fy0 * b) + 12582912.f), jy0 = __float_as_int((fx0 * b + fy0 * a) + 12582912.f);
-        const int jx1 = __float_as_int((fx1 * a - fy1 * b) + 12582912.f), jy1 = __float_as_int((fx1 * b + fy1 * a) + 12582912.f);
-        int t0 = patch[__mul24(cym + jy0, ppitch) + cxm + jx0];  // 24-bit multiply-add: full rate, unlike v_mul_lo_u32
-        int t1 = patch[__mul24(cym + jy1, ppitch) + cxm + jx1];
-        val |= (t0 < t1 ? 1u : 0u) << k;
-    }
-    return (uint16_t)val;  // little endian: bits 0..7 = byte 2gl, bits 8..15 = byte 2gl+1
-}
-
-// The same 16 tests per lane for the tile kernel.  pat: the pattern as floats in LDS, test-major interleaved so that the 16 lanes
+// 256 rotated binary tests out of an LDS tile, 16 per lane of a 16-lane group (lane gl produces descriptor bytes 2 gl, 2 gl + 1).  pat: the pattern as floats in LDS, test-major interleaved so that the 16 lanes
 // of a group read 16 consecutive float4 rows per test (conflict-free ds_read_b128, the four groups of a wavefront read the same rows:
 // broadcast) - no int8 -> float conversion per keypoint (64 half-rate v_cvt per lane before).  lds_base: LDS byte address of the
 // sample (cx, cy) of the blurred tile; the sample address is ONE v_mad_i32_i24 per point: the rounding bias 0x4B400000 of jx and its
@@ -1304,143 +1199,8 @@ __device__ __forceinline__ uint16_t rbrief_u16_lds(uint32_t lds_base, int ppitch
     return (uint16_t)val;
 }
 
-// One 16-lane group (a quarter wavefront) per keypoint.  The 31x31 raw patch (intensity centroid) and the 39x39 blurred
-// patch (rBRIEF) pass through the same group-private LDS patch one after the other: all global loads of both windows are
-// issued up front into registers, the raw window is stored and reduced to the angle while the blurred one is still in
-// flight, then the blurred window takes its place.  A patch is only touched by the 16 lanes of its group, which sit in
-// one wavefront and execute in lockstep, so no barrier is needed.  1716 B of LDS per keypoint (27 KB per workgroup,
-// 5 workgroups per CU).  Measured bound: vector issue (~1300 instructions per wavefront) with the LDS 75 % busy;
-// ablating any one phase (angle loop, sincos, the 256 tests) moves the kernel by 2-7 % only.
-template <bool HAS_DESC>  // compile-time: a run-time branch around the blurred loads would hide their count from s_waitcnt
-__global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
-                                                  const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
-                                                  const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
-                                                  uint8_t* __restrict__ desc, int cap, int* __restrict__ counts,
-                                                  int* flags, const int* __restrict__ lv_tab, uint32_t inv_per) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DK_PER_WG * DP_PATCH_BYTES];
-    __shared__ int s_lv[MO_MAX_LEVELS][DLV_N];
-    __shared__ __attribute__((aligned(16))) uint32_t s_icw[32][16];  // intensity-centroid weights of the 31 disc rows (+ a zero row)
-    // XCD affinity (speed only, any mapping is correct): consecutive workgroup ids go round-robin to the 8 XCDs, each with
-    // its own L2.  Re-indexing so that all workgroups of a frame share one id residue keeps the frame's two pyramids
-    // (2 MB) in ONE L2 while its keypoints are described, instead of being fetched into eight.
-    int frame = blockIdx.y, wg = blockIdx.x;
-    xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, wg);  // XCD affinity (speed only)
-    const int grp = threadIdx.x / DG, gl = threadIdx.x % DG;
-    const int k = wg * DK_PER_WG + grp;
-    // The kernel is bound by its chain of DEPENDENT memory round trips times the few keypoints a CU holds in flight (round 1: a
-    // scalar load + wait per level to find the keypoint's level, then the level's geometry out of the kernel arguments, then
-    // the keypoint record, then the patches: ~11 round trips).  Now: the per-level counts of the frame (wave-uniform, all
-    // issued at once) and the level table (copied to LDS) travel together, then the record, then the patches: 3.
-    if (threadIdx.x < MO_MAX_LEVELS * DLV_N) (&s_lv[0][0])[threadIdx.x] = lv_tab[threadIdx.x];
-    (&s_icw[0][0])[threadIdx.x] = (uint32_t)lv_tab[MO_MAX_LEVELS * DLV_N + threadIdx.x];
-    (&s_icw[0][0])[threadIdx.x + 256] = (uint32_t)lv_tab[MO_MAX_LEVELS * DLV_N + 256 + threadIdx.x];
-    const int* fc = fin_cnt + (size_t)frame * MO_MAX_LEVELS;
-    int cn[MO_MAX_LEVELS];
-#pragma unroll
-    for (int l = 0; l < MO_MAX_LEVELS; l++) cn[l] = fc[l];  // (entries past nlevels are ignored below)
-    __syncthreads();
-    int total = 0, L = -1, idx = 0;
-#pragma unroll
-    for (int l = 0; l < MO_MAX_LEVELS; l++) {
-        const int n = l < P.nlevels ? cn[l] : 0;
-        if (L < 0 && k < total + n) { L = l; idx = k - total; }
-        total += n;
-    }
-    if (k == 0 && gl == 0) {
-        counts[frame] = total;
-        if (total > cap) atomicOr(&flags[0], 2);
-    }
-    if (L < 0 || k >= cap) return;  // uniform within the group; no barriers below
-    uint8_t* s_p = s_patch + grp * DP_PATCH_BYTES;
-    struct { int pitch, off, bpitch, boff, fin_off; float scale; } lv;  // the level's geometry from the LDS copy of the table
-    lv.pitch = s_lv[L][DLV_PITCH]; lv.off = s_lv[L][DLV_OFF]; lv.bpitch = s_lv[L][DLV_BPITCH]; lv.boff = s_lv[L][DLV_BOFF];
-    lv.fin_off = s_lv[L][DLV_FIN_OFF]; lv.scale = __int_as_float(s_lv[L][DLV_SCALE]);
-    const FinalKp fk = fin_all[(size_t)frame * P.fin_stride + lv.fin_off + idx];
-    const int x = fk.x, y = fk.y;
-    const float px = (float)x * lv.scale, py = (float)y * lv.scale;
-    const uint8_t* img = L == 0 ? gray + (size_t)frame * P.w * P.h : pyr + (size_t)frame * P.pyr_stride + lv.off;
-    // aligned 9-dword (11-dword) window start, moved left when it would cross the end of the row
-    const bool al_raw = (lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0 && lv.pitch >= 36;
-    const int xr0 = al_raw ? min((x - 15) & ~3, lv.pitch - 36) : (x - 15) & ~3, offr = (x - 15) - xr0;
-    // half-widths of the two disc rows of this lane: fetched before the patch loads, whose s_waitcnt they would otherwise share
-    const int dsc0 = P.umax[15 - gl], dsc1 = P.umax[min(gl + 1, 15)];
-    uint32_t raw[PatchMap<31, 9>::N], blr[PatchMap<39, 11>::N];
-    patch_load<31, 9>(img, lv.pitch, xr0, y - 15, gl, al_raw, raw);
-    int offb = 0;
-    if (HAS_DESC) {
-        const float inv = 1.f / lv.scale;
-        const int cx = __float2int_rn(px * inv), cy = __float2int_rn(py * inv);
-        const uint8_t* bl = blur + (size_t)frame * P.blur_stride + lv.boff;
-        const int xb0 = min((cx - 19) & ~3, lv.bpitch - 44);
-        offb = (cx - 19) - xb0;
-        patch_load<39, 11>(bl, lv.bpitch, xb0, cy - 19, gl, true, blr);
-    }
-    patch_store<31, 9>(s_p, DP_RAW_PITCH, gl, raw);
-    // intensity centroid over the radius-15 disc: rows gl and gl + 16 of the 31 on each lane.  A row is read as nine dwords,
-    // realigned so that dword c holds u = 4c - 15 .. 4c - 12, and reduced with two v_dot4_u32_u8 per dword against the row's
-    // weight bytes (u + 16 inside the disc, else 0) and mask bytes (1 inside): sum u p = dot(w) - 16 dot(mask).  The byte
-    // loop this replaces ran max over the lanes of (2 d0 + 1) + (2 d1 + 1) = 54 trips of six instructions.
-    int m10 = 0, m01 = 0;
-    if (offr <= 3) {  // group-uniform (always, unless the window was moved left at the end of a row)
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int row_i = gl + rr * DG;  // row 31: all-zero weights, the dwords read lie inside the group's patch buffer
-            const uint32_t* rowp = (const uint32_t*)(s_p + row_i * DP_RAW_PITCH);
-            const uint4 w0 = *(const uint4*)&s_icw[row_i][0], w1 = *(const uint4*)&s_icw[row_i][4];
-            const uint4 k0 = *(const uint4*)&s_icw[row_i][8], k1 = *(const uint4*)&s_icw[row_i][12];
-            const uint32_t wt[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            const uint32_t mk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-            uint32_t px[9];
-#pragma unroll
-            for (int c4 = 0; c4 < 9; c4++) px[c4] = rowp[c4];
-            uint32_t sw = 0, rs = 0;
-#pragma unroll
-            for (int c4 = 0; c4 < 8; c4++) {
-                const uint32_t a = __builtin_amdgcn_alignbyte(px[c4 + 1], px[c4], (uint32_t)offr);
-                sw = __builtin_amdgcn_udot4(a, wt[c4], sw, false);
-                rs = __builtin_amdgcn_udot4(a, mk[c4], rs, false);
-            }
-            m10 += (int)sw - 16 * (int)rs;
-            m01 += (row_i - 15) * (int)rs;
-        }
-    } else {
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int row_i = gl + rr * DG;
-            if (row_i < 31) {
-                const int v = row_i - 15;
-                const int d = rr == 0 ? dsc0 : dsc1;
-                const uint8_t* row = s_p + row_i * DP_RAW_PITCH + 15 + offr;
-                int rs = 0;
-                for (int u = -d; u <= d; u++) {
-                    int p = row[u];
-                    m10 += u * p;
-                    rs += p;
-                }
-                m01 += v * rs;
-            }
-        }
-    }
-    m10 = group_sum(m10);
-    m01 = group_sum(m01);
-    const float angle = fast_atan2_deg((float)m01, (float)m10);
-    mo_keypoint* o = kps + (size_t)frame * cap + k;
-    if (gl == 0) {
-        o->x = px; o->y = py;
-        o->size = 31 * lv.scale;
-        o->angle = angle;
-        o->response = fk.response;
-        o->octave = L;
-        o->class_id = -1;
-    }
-    if (HAS_DESC) {  // patch-local centre (19 + offb, 19); bounds guaranteed by edge_threshold >= 19 and pattern radius <= 18
-        patch_store<39, 11>(s_p, DP_BLR_PITCH, gl, blr);
-        *(uint16_t*)(desc + ((size_t)frame * cap + k) * 32 + 2 * gl) = rbrief_u16(s_p, DP_BLR_PITCH, 19 + offb, 19, angle, gl);
-    }
-}
-
 // ------------------------------------------------------------------ describe, tile form (round 3) -------------------
-// The per-keypoint kernel above gathers two private windows per keypoint from global memory (31 x 36 B raw + 39 x 44 B blurred in
+// The per-keypoint kernel of rounds 1 - 2 (k_describe, removed; `git show 8789e68:visual-slam_amd/csrc/orb_kernels.hip`) gathered two private windows per keypoint from global memory (31 x 36 B raw + 39 x 44 B blurred in
 // 48 dword loads per lane: ~130 cache-line requests per keypoint, 1.45 GB through the vector L1 per 256-frame launch, a wavefront
 // spent 8 - 21 k of its 30 k cycles waiting for them) and parks them in LDS through registers (93 VGPRs, 5 wavefronts per SIMD).
 // Here a workgroup owns a 128 x 64 TILE of one level's border region: it picks the level's final keypoints that fall into the tile
@@ -1450,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_describe(Plan P, const uint8_t* __restr
 //   * no window registers: the per-row intensity-centroid weights (constant per lane) live in registers instead of being re-read
 //     from LDS for every keypoint, ~70 VGPRs
 //   * tile pitches of 25 / 27 dwords (odd): the 16 lanes of a group read 16 different rows conflict-free in the centroid phase
-// Results are those of k_describe bit for bit (same integer sums, same float expressions, same sample addresses).
+// Results are those of that kernel bit for bit (same integer sums, same float expressions, same sample addresses).
 #ifndef DT_W
 #define DT_W 128   // measured on MI355X (profiles/r03_ab_describe.txt): 64 x 64 tiles of 128 threads 0.334 ms, 128 x 64 tiles of 256 threads 0.273 ms
 #endif
@@ -1755,46 +1515,7 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles_rare(Plan P, const uin
     }
 }
 
-static int orb_launch_describe_patch(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap,
-                        int* d_counts) {
-    const Plan& P = c->plan;
-    const dim3 grid((cap + DK_PER_WG - 1) / DK_PER_WG, batch);
-    if (!c->d_lv_tab) {  // (re)built with the plan: free_plan_buffers drops it
-        int tab[MO_MAX_LEVELS * DLV_N + 512] = {0};  // level table, then the intensity-centroid weights [32 rows][8 weight + 8 mask dwords]
-        for (int r = 0; r < 31; r++) {
-            const int d = P.umax[r < 15 ? 15 - r : r - 15];
-            for (int c4 = 0; c4 < 8; c4++) {
-                uint32_t wv = 0, mv = 0;
-                for (int b = 0; b < 4; b++) {
-                    const int u = 4 * c4 - 15 + b;
-                    if (u >= -d && u <= d) { wv |= (uint32_t)(u + 16) << (8 * b); mv |= 1u << (8 * b); }
-                }
-                tab[MO_MAX_LEVELS * DLV_N + r * 16 + c4] = (int)wv;
-                tab[MO_MAX_LEVELS * DLV_N + r * 16 + 8 + c4] = (int)mv;
-            }
-        }
-        for (int L = 0; L < P.nlevels; L++) {
-            int* e = tab + L * DLV_N;
-            e[DLV_PITCH] = P.lv[L].pitch; e[DLV_OFF] = P.lv[L].off; e[DLV_BPITCH] = P.lv[L].bpitch; e[DLV_BOFF] = P.lv[L].boff;
-            e[DLV_FIN_OFF] = P.lv[L].fin_off; std::memcpy(&e[DLV_SCALE], &P.lv[L].scale, sizeof(float));
-        }
-        HIPCHK(c, hipMalloc((void**)&c->d_lv_tab, sizeof(tab)));
-        HIPCHK(c, hipMemcpy(c->d_lv_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
-    }
-    const uint32_t inv_per = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
-    if (d_desc)
-        hipLaunchKernelGGL(k_describe<true>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
-                           d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_lv_tab, inv_per);
-    else
-        hipLaunchKernelGGL(k_describe<false>, grid, dim3(256), 0, c->stream, P, d_gray, c->d_pyr, c->d_blur, c->d_fin, c->d_fin_cnt,
-                           d_kps, d_desc, cap, d_counts, c->flags_cur, c->d_lv_tab, inv_per);
-    HIPCHK(c, hipGetLastError());
-    return MO_OK;
-}
-
-
 int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_counts) {
-    if (c->describe_patch) return orb_launch_describe_patch(c, d_gray, batch, d_kps, d_desc, cap, d_counts);  // VSLAM_AMD_DESCRIBE=patch (A/B timing)
     const Plan& P = c->plan;
     if (!c->d_dtile_tab) {  // (re)built with the plan: free_plan_buffers drops it
         // tile table (level | tile column << 8 | tile row << 20, level-major) followed by the intensity-centroid weights
