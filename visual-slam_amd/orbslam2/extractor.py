@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 import vslam_amd
-from .types import KeyPoint, keypoints_from_array, keypoints_to_array
+from .types import KeyPoint, keypoints_at, keypoints_from_array, keypoints_to_array
 
 
 def _default_order():
@@ -83,7 +83,7 @@ class ORBExtractor:
         xy, kept, descriptors = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features)
         if aligned:
             xy = xy[kept]
-        all_keypoints = [KeyPoint(x, y, 31) for x, y in xy.tolist()]  # (tolist: Python floats at once, not a numpy scalar per field)
+        all_keypoints = keypoints_at(xy, 31)  # a list, like the reference's (bulk conversion, slots filled directly)
         if not len(kept):
             descriptors = None
         return all_keypoints, descriptors

@@ -137,6 +137,21 @@ def keypoints_from_array(arr):
     return KeyPointSeq(arr)
 
 
+def keypoints_at(xy, size=31.0):
+    """[KeyPoint(x, y, size) for x, y in xy] (the reference's distribute_keypoints list, extractor.py:133) with the stand-in's slots
+    filled directly: cv2's defaults angle -1, response 0, octave 0, class_id -1"""
+    rows = xy.tolist()
+    if HAVE_CV2:
+        return [KeyPoint(x, y, size) for x, y in rows]
+    new, out, size = object.__new__, [], float(size)
+    append = out.append
+    for x, y in rows:
+        k = new(KeyPoint)
+        k.pt = (x, y); k.size = size; k.angle = -1.0; k.response = 0.0; k.octave = 0; k.class_id = -1
+        append(k)
+    return out
+
+
 def keypoints_to_array(kps):
     import numpy as np
     from vslam_amd import KP_DTYPE
