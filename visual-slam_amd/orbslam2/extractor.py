@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 import vslam_amd
-from .types import KeyPoint, keypoints_at, keypoints_from_array, keypoints_to_array
+from .types import keypoints_at, keypoints_from_array, keypoints_to_array
 
 
 def _default_order():
