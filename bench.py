@@ -34,8 +34,12 @@ sys.path.insert(0, os.path.join(ROOT, "visual-slam_amd"))
 
 W, H, NFEAT, CAP = 640, 480, 2000, 2048
 N_HYP = 4096
-PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy rate
-PMC_FILE = "profiles/r03_pmc_per_kernel.json"  # rocprofv3 --pmc passes of profiles/collect_r03.sh on this build and scene
+PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PEAK_HBM_MEASURED_GBPS = 6290.0  # measured copy rate of the same guide (SURVEY 8d asks for both)
+PMC_FILE = "profiles/r04_pmc_per_kernel.json"  # rocprofv3 --pmc passes of profiles/collect.sh on this build and scene
+# SURVEY 8d's whole-pipeline byte models: stage-materialised extraction (pyramid and blurred pyramid each written once and read once),
+# the fused-ideal lower bound (input + outputs only), and the matcher's bytes per pair
+SURVEY_EXTRACT_BYTES, SURVEY_FUSED_IDEAL_BYTES, SURVEY_MATCH_BYTES = 4541474, 427200, 162000
 
 # algorithmic bytes per frame of each extraction stage (stage-materialised model)
 STAGE_BYTES = {
@@ -210,6 +214,8 @@ def main():
     force_gather = world == 1 and os.environ.get("BENCH_FORCE_GATHER") == "1"
     rccl = {"on": (world > 1 and args.backend == "nccl") or force_gather}
 
+    status = {}   # leg -> mo_dev_status word read after the leg (all 0, asserted)
+
     class Pipeline:
         """This rank's context, input frames and output buffers for nb frames (n_pairs = nb - 1 consecutive pairs)."""
 
@@ -240,6 +246,14 @@ def main():
 
         def launch(self):
             self.ctx._check(self.ctx.lib.mo_dev_frontend_batch(self.ctx.h, C.byref(prm), C.byref(self.io)))
+
+        def check(self, leg):
+            """after a leg's synchronisation: no capacity flag was raised by any call of the leg (a clamped overflow would otherwise
+            pass unnoticed: the kernels never fault, they clamp and raise a bit) and the outputs are populated"""
+            st = self.ctx.dev_status()
+            assert st == 0, "leg %s: mo_dev_status = %d (capacity flag raised inside a timed region)" % (leg, st)
+            status[leg] = st
+            assert int(self.counts.min().item()) > 0, "leg %s: a frame without keypoints" % leg
 
         def stage_ms(self, n_calls):
             acc, n = {}, min(n_calls, V.TIMING_SLOTS)
@@ -377,6 +391,7 @@ def main():
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             elapsed = float(te.item())
+        pl.check("headline_%d" % B)
         if rccl["on"] and rank == 0:  # the gathered slabs are what the ranks computed: row counts and rank 0's own slab
             assert ga.rows_all.cpu().tolist() == pairs_all, (ga.rows_all.cpu().tolist(), pairs_all)
             k_last = ga.k ^ 1
@@ -404,7 +419,10 @@ def main():
         mpass_mean = float(pl.mpass.sum(dim=1).float().mean().item())
         per_stage = pl.stage_ms(args.steps)
         units_of = lambda k: n_pairs if k in ("match_knn2_ratio", "two_view") else nb
-        total_alg = sum(STAGE_BYTES.get(k, 0) * units_of(k) for k in per_stage)
+        # pipeline bytes on SURVEY 8d's model (4 541 474 B per frame + 162 000 B per matched pair); the per-stage table below keeps its
+        # own per-stage bytes (it charges the blur its reads too, which the blueprint's whole-pipeline model does not)
+        total_alg = SURVEY_EXTRACT_BYTES * nb + SURVEY_MATCH_BYTES * n_pairs
+        fused_alg = SURVEY_FUSED_IDEAL_BYTES * nb + SURVEY_MATCH_BYTES * n_pairs
         # roofline of the image kernel with the longest time: k_fast.  Every kernel runs in line on one stream (the blur too), so the
         # hipEvent span of a stage in the timed region IS its kernels' own duration.
         crit = "fast_nms"
@@ -456,11 +474,19 @@ def main():
                        "rccl_ranks": world if rccl["on"] else 0},
             "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(achieved / PEAK_HBM_GBPS, 5), "hbm_frac": round(achieved / PEAK_HBM_GBPS, 5),
+                         "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": round(achieved / PEAK_HBM_MEASURED_GBPS, 5),
                          "valu_frac": round(valu_frac, 4) if valu_frac else None, "traffic": traffic,
                          "traffic_source": (PMC_FILE + " (separate rocprofv3 --pmc passes of the same command, not this run)") if traffic else None,
                          "algorithmic_bytes": alg_bytes, "kernel_ms": round(crit_ms, 4),
                          "kernel_ms_source": "hipEvent span in the timed region (every kernel in line on one stream)",
                          "pipeline_achieved": round(total_alg / (ms_step * 1e-3) / 1e9, 2),
+                         "pipeline_bytes_model": "SURVEY 8d stage-materialised: %d B/frame + %d B/pair" % (SURVEY_EXTRACT_BYTES, SURVEY_MATCH_BYTES),
+                         "pipeline_frac": round(total_alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                         "pipeline_frac_of_measured": round(total_alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_MEASURED_GBPS, 5),
+                         "fused_ideal": {"bytes_per_frame": SURVEY_FUSED_IDEAL_BYTES, "achieved": round(fused_alg / (ms_step * 1e-3) / 1e9, 2),
+                                         "frac": round(fused_alg / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                                         "note": "SURVEY 8d fused-ideal lower bound (input 307 200 B + outputs 120 000 B per frame, + the "
+                                                 "matcher's bytes): what a pipeline that never materialised a pyramid would have to move"},
                          "note": "k_fast = the image kernel with the longest time; algorithmic bytes (SURVEY 8d: 950 532 B per frame) / its "
                                  "own duration.  valu_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz x duration); "
                                  "tools/ubench.hip measures 2.3 cycles only for add/sub/logic/shift-right/f32 add-mul and 4.5 for every other "
@@ -474,7 +500,7 @@ def main():
             out["config5_512_per_gpu"] = second
         single = world == 1 and not args.no_extras
 
-        def timed_calls(n_warm=None):
+        def timed_calls(leg, n_warm=None):
             """W warm-up + K timed launches of the headline pipeline in its current configuration -> (seconds, stage ms)"""
             t_pw = time.perf_counter()
             while (time.perf_counter() - t_pw) * 1e3 < args.prewarm_ms:
@@ -487,14 +513,16 @@ def main():
             for _ in range(args.steps):
                 pl.launch()
             torch.cuda.synchronize()
-            return time.perf_counter() - t1, pl.stage_ms(args.steps)
+            el = time.perf_counter() - t1
+            pl.check(leg)
+            return el, pl.stage_ms(args.steps)
 
         if single:
             # (s) the other scene on the headline context (input pointer switched)
             other = "smooth" if args.scene == "survey8d" else "survey8d"
             fr2 = make_frames(torch, dev, 0, nb, scene=other)
             pl.io.d_gray = fr2.data_ptr()
-            el_s, st_s = timed_calls()
+            el_s, st_s = timed_calls("scene_" + other)
             out["scene_" + other] = {"value": round(B * args.steps / el_s, 2), "unit": "frames/s", "ms_per_step": round(el_s / args.steps * 1e3, 3),
                                      "keypoints_per_frame_mean": float(pl.counts.float().mean().item()),
                                      "matches_per_pair_mean": float(pl.mpass.sum(dim=1).float().mean().item()),
@@ -518,6 +546,7 @@ def main():
                 pl2.launch()
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
+            pl2.check("matcher_mfma_optin")
             m_ms = pl2.stage_ms(args.steps).get("match_knn2_ratio", 0.0)
             c64 = pl2.counts.cpu().numpy().astype(np.float64)
             ops = float((c64[:-1] * c64[1:]).sum()) * 512.0
@@ -537,7 +566,7 @@ def main():
             seln = torch.zeros(n_pairs, dtype=torch.int32, device=dev)
             pl.io.mode = V.MODE_TRACK; pl.io.disp_frac = 0.02; pl.io.thr_px = 1.0
             pl.io.d_sel_idx = sel.data_ptr(); pl.io.d_sel_n = seln.data_ptr()
-            elt, acct = timed_calls()
+            elt, acct = timed_calls("track_mode")
             out["next_rows"] = {"track_mode": {"value": round(B * args.steps / elt, 2), "unit": "frames/s", "ms_per_step": round(elt / args.steps * 1e3, 3),
                                                "kept_matches_per_pair_mean": float(seln.float().mean().item()),
                                                "stage_ms": {k: round(v, 4) for k, v in acct.items()}}}
@@ -562,6 +591,7 @@ def main():
                 h2d_step()
             torch.cuda.synchronize()
             el3 = time.perf_counter() - t1
+            pl.check("h2d_inclusive")
             # (a') the same with the copy of batch i + 1 overlapped with the compute of batch i: two device buffers, a copy stream,
             #      events both ways (compute waits for its buffer's copy, the copy waits until the buffer's last reader is done)
             copy_s = torch.cuda.Stream(device=dev)
@@ -589,6 +619,7 @@ def main():
                 freed[k].record(main_s)
             torch.cuda.synchronize()
             el4 = time.perf_counter() - t1
+            pl.check("h2d_overlapped")
             pl.io.d_gray = pl.frames.data_ptr()
             out["h2d_inclusive"] = {"value": round(B * args.steps / el3, 2), "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 3),
                                     "overlapped_value": round(B * n_ov / el4, 2), "overlapped_ms_per_step": round(el4 / n_ov * 1e3, 3),
@@ -625,6 +656,7 @@ def main():
                         "returns a lazy KeyPoint sequence (objects are built when a caller indexes or iterates it: the *_all_objects "
                         "row forces all 2000); the *_native_arrays rows stop at numpy arrays; tracker_frame = what a Tracker pays per "
                         "frame in TRACKING state through the classes: detect_and_compute + track_from_last_frame (tracker.py:87,198-266)"}
+        out["dev_status"] = dict(status, note="mo_dev_status after every leg's synchronisation: 0 = no capacity flag raised (asserted)")
         if not args.no_cpu_baseline and world == 1:
             nf = min(args.cpu_frames, nb)
             out["cpu_baseline"] = cpu_baseline(pl.frames[:nf].cpu().numpy(), nf, K)
@@ -655,7 +687,7 @@ def next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K):
     # 8x8 grid of Shi-Tomasi corners + orb.compute at angle -1, as one batched call on the same frames (MO_DETECT_GRID), followed by
     # the same match + two-view stages
     pl.io.detector = V.DETECT_GRID
-    elg, stg = timed_calls()
+    elg, stg = timed_calls("grid_mode")
     legs["grid_mode"] = {"value": round(pl.n * args.steps / elg, 2), "unit": "frames/s", "ms_per_step": round(elg / args.steps * 1e3, 3),
                          "keypoints_per_frame_mean": float(pl.counts.float().mean().item()),
                          "matches_per_pair_mean": float(pl.mpass.sum(dim=1).float().mean().item()),
@@ -672,7 +704,7 @@ def next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K):
     dP1 = torch.from_numpy(np.ascontiguousarray(Pm[:-1].reshape(-1, 12))).to(dev); dP2 = torch.from_numpy(np.ascontiguousarray(Pm[1:].reshape(-1, 12))).to(dev)
     pl.io.mode = V.MODE_KEYFRAME; pl.io.ratio = 0.8; pl.io.n_kf_pairs = len(kf) - 1
     pl.io.d_kf_query = q.data_ptr(); pl.io.d_kf_train = t.data_ptr(); pl.io.d_kf_P1 = dP1.data_ptr(); pl.io.d_kf_P2 = dP2.data_ptr()
-    elk, stk = timed_calls()
+    elk, stk = timed_calls("keyframe_mode")
     legs["keyframe_mode"] = {"value": round(pl.n * args.steps / elk, 2), "unit": "frames/s", "ms_per_step": round(elk / args.steps * 1e3, 3),
                              "keyframe_pairs": len(kf) - 1, "inliers_per_pair_mean": float(pl.npts[:len(kf) - 1].float().mean().item()),
                              "stage_ms": {k: round(v, 4) for k, v in stk.items()},
@@ -680,6 +712,7 @@ def next_row_legs(torch, V, pl, prm, dev, args, timed_calls, n_pairs, K):
     pl.io.mode = V.MODE_INIT; pl.io.ratio = 0.75; pl.io.n_kf_pairs = 0
     pl.launch()  # (the legs below read the headline configuration's outputs again)
     torch.cuda.synchronize()
+    pl.check("restore_headline")
     return legs
 
 

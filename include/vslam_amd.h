@@ -154,6 +154,60 @@ int mo_track_pair(mo_ctx*, const mo_keypoint* kps1, int n1, const uint8_t* desc1
                   int n_hyp, uint64_t seed, double R[9], double t[3], double E[9], int32_t* sel_idx, int32_t* sel_dist,
                   int* n_sel, uint8_t* inlier, int* n_inliers);
 
+/* ---- one frame at a time: resident results and the fused pair step -------------------------------------------------------------
+ * The reference's Tracker calls the classes once per frame (tracker.py:87 extract_features, then :168-170 initialize or :214-254
+ * _track_from_last_frame against the PREVIOUS frame's keypoints and descriptors; tests/tester_map.py:57-75 is that loop).  A
+ * single-frame mo_orb_detect_compute (batch == 1, desc != NULL) therefore leaves its keypoints and descriptors RESIDENT on the device
+ * (the context keeps the last 4 such results) and mo_last_token names them; mo_pair_frontend runs matcher -> (tracking filters) ->
+ * two-view stage on two frames given by token - nothing is uploaded - or by host arrays (uploaded into a slot; out->token1 / token2
+ * then name them for the next call).  One call, one synchronisation:
+ *   MO_MODE_INIT   MapInitializer.initialize's device work (initializer.py:67-120): matcher.match(d1, d2) with `ratio`, essential matrix at
+ *                  thr_px (the reference passes 3.0) on the ratio-test survivors in query order, recoverPose, triangulation
+ *   MO_MODE_TRACK  Tracker._track_from_last_frame (tracker.py:214-254): match, displacement filter (disp_frac of (w + h) / 2), 2 x median
+ *                  distance filter, essential matrix at thr_px (1.0) + recoverPose on the kept matches in the reference's order
+ * n_hyp = 0 stops after the matcher (and the filters).  A token that is no longer resident falls back to the arrays; MO_ERR_ARG when
+ * there are none. */
+typedef struct {
+    uint64_t token;          /* 0 = none */
+    const mo_keypoint* kps;  /* [n] host, may be NULL while the token is alive */
+    const uint8_t* desc;     /* [n][32] host */
+    int32_t n;
+} mo_frame_ref;
+
+typedef struct {
+    int32_t mode;            /* MO_MODE_INIT or MO_MODE_TRACK */
+    int32_t w, h;            /* image size (MO_MODE_TRACK: the displacement gate) */
+    double ratio;            /* Lowe ratio; negative = no ratio test */
+    double disp_frac;        /* MO_MODE_TRACK: threshold_percent (tracker.py:219: 0.02) */
+    double K[9];
+    double thr_px;
+    int32_t n_hyp;           /* 0 = matcher (+ filters) only */
+    uint64_t seed;
+    uint64_t pair_index;     /* global index of this pair in a sequence: the sampling stream is a function of (seed, pair_index), so a
+                                per-frame loop that counts its pairs gets the poses of the batched mode bit for bit; 0 = stand-alone pair */
+} mo_pair_params;
+
+typedef struct {
+    /* caller-allocated arrays; n1 = keypoints of frame 1; any of them may be NULL */
+    int32_t* match_idx;      /* [n1][2] knn train indices (missing neighbour: -1) */
+    int32_t* match_dist;     /* [n1][2] */
+    uint8_t* match_pass;     /* [n1] ratio test */
+    int32_t* sel_idx;        /* MO_MODE_TRACK: [n1][2] (queryIdx, trainIdx) of the kept matches, ascending distance */
+    int32_t* sel_dist;       /* MO_MODE_TRACK: [n1] */
+    uint8_t* inlier;         /* MO_MODE_TRACK: [n_sel] recoverPose mask per kept match; MO_MODE_INIT: [n1] pose mask per QUERY keypoint */
+    uint8_t* ransac;         /* MO_MODE_INIT: [n1] findEssentialMat mask per query keypoint */
+    float* X;                /* MO_MODE_INIT: [n1][3] map point per query keypoint (NaN = none) */
+    /* filled by the call */
+    double R[9], t[3], E[9]; /* NaN without a model (MO_MODE_TRACK: fewer than 8 kept matches, tracker.py:234) */
+    int32_t n_sel;           /* MO_MODE_TRACK: kept matches */
+    int32_t n_good;          /* recoverPose inliers */
+    int32_t n1, n2;          /* keypoints of the two frames */
+    uint64_t token1, token2; /* tokens under which the two frames are resident now */
+} mo_pair_out;
+
+int mo_last_token(mo_ctx*, uint64_t* token); /* token of the last single-frame mo_orb_detect_compute with descriptors (0: none) */
+int mo_pair_frontend(mo_ctx*, const mo_frame_ref* f1, const mo_frame_ref* f2, const mo_pair_params*, mo_pair_out*);
+
 /* Replaces cv2.triangulatePoints(P1, P2, pts1, pts2)   (utils.py:56-60): per-point 4x4 DLT null vector.
  * P1, P2 row-major 3x4 f64; p1, p2 [n][2] f32; X4 [n][4] f32 homogeneous (unit norm, sign arbitrary -
  * the reference divides by w, utils.py:62-70). */
@@ -272,12 +326,23 @@ int mo_stage_times(mo_ctx*, const char*** names, float* ms, int cap);
  * instead of waiting for every call's last event (bench.py's timed region). */
 int mo_stage_times_back(mo_ctx*, int back, const char*** names, float* ms, int cap);
 
+/* Host-side clock of the last single-call host entry point (mo_orb_detect_compute, mo_match_knn2_ratio, mo_track_pair, mo_init_two_view),
+ * microseconds: us[0] entry -> everything enqueued (staging copies, launches), us[1] the wait for the stream, us[2] unpacking into
+ * the caller's arrays, us[3] the whole call.  With mo_stage_times (device spans incl. the "h2d" / "d2h" copies) this is the batch-1
+ * latency breakdown bench.py reports (single_frame_ms.breakdown). */
+int mo_host_times(mo_ctx*, double us[4]);
+/* Stage events inside the single-call host entry points (off by default: an event between two kernels idles the GPU for ~ 4.5 us,
+ * five of them were 9 % of a single-frame extraction; the mo_dev_* calls always record theirs).  on != 0: mo_stage_times reports the
+ * spans of the next host calls ("h2d", the kernel stages, "d2h"). */
+int mo_set_host_timing(mo_ctx*, int on);
+
 /* internal-stage probes used by the parity tests (device pipeline, host in/out) */
 int mo_dbg_pyramid_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level, int blurred,
                          uint8_t* out /* lw*lh */, int* lw, int* lh);
 int mo_dbg_fast_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level,
                       int32_t* xys /* [cap][3] */, int cap, int* n);
 int mo_dbg_min_eigen(mo_ctx*, const uint8_t* gray, int w, int h, float* eig /* [h*w] */);
+int mo_dbg_set_poison(mo_ctx*, int byte /* 0..255: the pyramid buffers are filled with it before every extraction; -1: off */);
 int mo_dbg_retain_best(mo_ctx*, const float* resp, int n, int n_points, int select_order, int32_t* order, int* n_out);
 
 #ifdef __cplusplus

@@ -28,20 +28,29 @@ def test_struct_layouts():
     assert C.sizeof(V.OrbParams) == 40
 
 
-def test_batch_io_layout_matches_the_header(tmp_path):
-    """sizeof / offsetof of mo_batch_io as a C compiler sees include/vslam_amd.h == the ctypes mirror (fields are appended per round)."""
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct that crosses the boundary as a C compiler sees include/vslam_amd.h == the ctypes mirror
+    (mo_batch_io gets fields appended per round; mo_frame_ref / mo_pair_params / mo_pair_out are the one-frame-at-a-time API)."""
     import ctypes as C
     import subprocess
     import vslam_amd as V
-    fields = [f[0] for f in V.BatchIO._fields_]
+    structs = [("mo_batch_io", V.BatchIO), ("mo_orb_params", V.OrbParams), ("mo_frame_ref", V.FrameRef), ("mo_pair_params", V.PairParams),
+               ("mo_pair_out", V.PairOut)]
+    body = ""
+    for cname, cls in structs:
+        body += '  printf("%%zu\\n", sizeof(%s));\n' % cname
+        body += "".join('  printf("%%zu\\n", offsetof(%s, %s));\n' % (cname, f[0]) for f in cls._fields_)
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vslam_amd.h"\nint main(void) {\n  printf("%zu\\n", sizeof(mo_batch_io));\n' +
-                   "".join('  printf("%%zu\\n", offsetof(mo_batch_io, %s));\n' % f for f in fields) + "  return 0;\n}\n")
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vslam_amd.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
-    assert got[0] == C.sizeof(V.BatchIO)
-    assert got[1:] == [getattr(V.BatchIO, f).offset for f in fields]
+    k = 0
+    for cname, cls in structs:
+        assert got[k] == C.sizeof(cls), cname
+        offs = [getattr(cls, f[0]).offset for f in cls._fields_]
+        assert got[k + 1:k + 1 + len(offs)] == offs, cname
+        k += 1 + len(offs)
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present")

@@ -526,6 +526,48 @@ def test_bench_workload_all_pairs_properties():
         assert (Xi[:, 2] > 0).all() and ((Xi @ R.T + t)[:, 2] > 0).all()      # in front of both cameras
         assert np.isnan(X[i, ~good]).all()
     assert np.median(err_R) < 2e-3 and np.median(dot_t) > 0.995 and np.percentile(dot_t, 5) > 0.95, (np.median(err_R), np.median(dot_t))
+    # The oracle on the bench generator's OWN frames (not a sibling scene): the pairs the kernels agree with ground truth worst on -
+    # the minimum of t . t_gt, the largest rotation error, pair 9 (0.8986 in round 3) - and four seeded random ones, HIP against
+    # geom_oracle.init_two_view on the same correspondences with the pair's own sampling stream at 1e-4; four frames against
+    # orb_oracle.detect_and_compute bit for bit.  The loose per-pair bound above (t . t_gt > 0.4) is therefore the DATA's limit (the
+    # oracle lands on the same pose: the z-component of a sideways translation is weakly observed), not slack for the kernels.
+    from oracle import geom_oracle as G
+    from oracle import orb_oracle as O
+    O.lib().orc_set_variant(0, 0)
+    rng = np.random.Generator(np.random.PCG64(4))
+    worst = {int(np.argmin(dot_t)), int(np.argmax(err_R)), 9} | {int(v) for v in rng.choice(nb - 1, 4, replace=False)}
+    fr_np = frames.cpu().numpy()
+    kp28 = b["kps"].cpu().numpy().view(np.uint8).reshape(nb, cap, 28)
+    for i in sorted(worst):
+        n = cn[i]
+        ps, idx = mp[i, :n], mi[i, :n]
+        p1 = kp[i, :n, :2][ps]
+        p2 = kp[i + 1, :cn[i + 1], :2][idx[ps, 0]]
+        o = G.init_two_view(p1, p2, K, thr_px=3.0, n_hyp=4096, seed=4096, pair=i)
+        R, t = P[i, :9].reshape(3, 3), P[i, 9:]
+        assert o["R"] is not None
+        assert np.linalg.norm(R - o["R"]) / np.linalg.norm(o["R"]) < 1e-4, "pair %d R vs oracle (t.t_gt = %.4f)" % (i, dot_t[i])
+        assert np.linalg.norm(t - o["t"].ravel()) < 1e-4, "pair %d t vs oracle (t.t_gt = %.4f)" % (i, dot_t[i])
+        q_of = np.nonzero(ps)[0]
+        gmask = ~np.isnan(X[i, q_of, 0])
+        assert (gmask != o["pose_mask"]).sum() <= 2 and abs(int(NP[i]) - o["n_good"]) <= 2, "pair %d pose mask vs oracle" % i
+        both = gmask & o["pose_mask"]
+        e = np.linalg.norm(X[i, q_of[both]] - o["X"][both], axis=1) / np.linalg.norm(o["X"][both], axis=1)
+        # this scene's points sit 19 and 38 baselines away (pan of 16.7 / 8.4 px per frame at f = 320): a relative pose difference d
+        # moves a point by about depth x d, so two poses inside the 1e-4 bound above leave the bulk of the points within 1e-4 of
+        # each other and the tail (measured on the worst pair, 116: 99th percentile 4e-3, maximum 7e-3) a few 1e-3 apart
+        worst = int(np.argmax(e))
+        info = "pair %d map points vs oracle: median %.2e, 99 %% %.2e, max %.2e at depth %.1f" % (
+            i, np.median(e), np.percentile(e, 99), e.max(), o["X"][both][worst, 2])
+        assert np.median(e) < 1e-4 and np.percentile(e, 75) < 1e-3 and e.max() < 5e-2, info
+    for f in sorted({0, int(np.argmin(dot_t)), 128, nb - 1}):
+        ek, ed = O.detect_and_compute(fr_np[f], O.params(nfeatures=2000))
+        n = cn[f]
+        assert n == len(ek), f
+        got = kp28[f, :n].reshape(-1).view(V.KP_DTYPE)
+        for fld in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            assert np.array_equal(got[fld], ek[fld]), (f, fld)
+        assert np.array_equal(b["desc"][f, :n].cpu().numpy(), ed), f
     ctx.close()
 
 
@@ -732,9 +774,8 @@ def test_grid_cells_with_more_local_maxima_than_one_sort_holds(name):
 @pytest.mark.parametrize("mode", ["init", "track"])
 def test_batched_rows_longer_than_4096(mode):
     """mo_dev_frontend_batch with 5000 features per frame (cap 5064) on 1280 x 720 frames: the two-view stage and the tracking filters
-    were refused for cap > 4096 until round 3 (MO_ERR_UNSUPPORTED for the whole call); what is limited is the number of
-    correspondences of ONE pair (4096: status bit 3, that pair gets no model), not the row length.  Keypoints equal the host call, the
-    pose of every pair equals the oracle on the same correspondences."""
+    were refused for cap > 4096 until round 3 (MO_ERR_UNSUPPORTED for the whole call).  Keypoints equal the host call, the pose of every
+    pair equals the oracle on the same correspondences.  (Pairs with more than 4096 CORRESPONDENCES: tests/test_gpu_frame_api.py.)"""
     import torch
     import vslam_amd as V
     from oracle import geom_oracle as G
@@ -786,35 +827,5 @@ def test_batched_rows_longer_than_4096(mode):
                 assert (s[:, 0] < nfeat).all() and (s[:, 0] >= 0).all() and s[:, 0].max() > 4096   # query indices beyond 12 bits survive the sort key
                 assert np.array_equal(s[:, 1], idx[s[:, 0], 0])
         host.close()
-    finally:
-        ctx.close()
-
-
-def test_pair_with_more_than_4096_correspondences_gets_no_model():
-    """the limit the two-view stage does have: more than 4096 correspondences in ONE pair (here two identical frames with 5000
-    features: every query passes the ratio test) -> status bit 3, NaN pose and no points for that pair, the other pair unaffected."""
-    import torch
-    import vslam_amd as V
-    from tests.helpers import parallax_frames
-    nb, cap, nfeat, w, h = 3, 5064, 5000, 1280, 720
-    frames = parallax_frames(nb, seed=62, w=w, h=h, bg_step=8, fg_step=16).copy()
-    frames[2] = frames[1]
-    dev = torch.device("cuda", 0)
-    ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=nb)
-    try:
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        prm = V.orb_params(nfeatures=nfeat)
-        io, b, _ = _batch_io(torch, V, dev, torch.from_numpy(frames).to(dev), nb, cap, 512)
-        io.w, io.h = w, h
-        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))
-        torch.cuda.synchronize()
-        assert ctx.dev_status() == 8
-        assert int(b["mpass"][1].sum().item()) == nfeat           # the identical pair: every query passes
-        P = b["pose"].cpu().numpy(); NP = b["npts"].cpu().numpy()
-        assert np.isfinite(P[0]).all() and NP[0] > 100 and np.isnan(P[1]).all() and NP[1] == 0
-        assert np.isnan(b["pts"][1].cpu().numpy()).all()
-        ctx._check(ctx.lib.mo_dev_frontend_batch(ctx.h, C.byref(prm), C.byref(io)))   # (the status word was cleared by the read)
-        torch.cuda.synchronize()
-        assert ctx.dev_status() == 8
     finally:
         ctx.close()

@@ -97,15 +97,19 @@ def _retain_cases():
             else: r = np.full(n, 3.0, np.float32)
             for k in sorted({0, 1, 2, n // 3, n // 2, n - 1, n, n + 5}):
                 cases.append((r, k))
-    # median-of-3 killer: drives libstdc++ introselect into its heap-select fallback
-    n = 4096
-    a = np.zeros(n, np.float32)
-    k = n // 2
-    for i in range(1, k + 1):
-        if i & 1:
-            a[i - 1] = i; a[i] = k + i
-        a[k + i - 1] = 2 * i
-    cases.append((-a, n // 2)); cases.append((a, n // 2)); cases.append((a, 10))
+    # median-of-3 killer: drives libstdc++ introselect into its heap-select fallback (n = 64 / 128: inside the register-resident tail)
+    for n in (64, 128, 4096):
+        a = np.zeros(n, np.float32)
+        k = n // 2
+        for i in range(1, k + 1):
+            if i & 1:
+                a[i - 1] = i; a[i] = k + i
+            a[k + i - 1] = 2 * i
+        cases.append((-a, n // 2)); cases.append((a, n // 2)); cases.append((a, 10))
+    # every size of the register-resident tail (ranges of 4 .. 64 records), tie-heavy and distinct
+    for n in range(4, 66):
+        cases.append((rng.integers(0, 5, size=n).astype(np.float32), n // 2))
+        cases.append((rng.normal(size=n).astype(np.float32), max(1, n // 3)))
     return cases
 
 
@@ -189,8 +193,8 @@ def test_level_margins_follow_the_edge_threshold(O, edge, scale, nlev, monkeypat
     O.lib().orc_set_variant(0, 0)
     ek, ed = O.detect_and_compute(img, o)
     assert len(ek) > 300
-    monkeypatch.setenv("VSLAM_AMD_POISON", "171")
     c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+    c._check(c.lib.mo_dbg_set_poison(c.h, 171))
     try:
         (k, d), = c.orb_detect_compute(img, p)
         for f in ("x", "y", "angle", "response", "octave"):
@@ -234,9 +238,9 @@ def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     p, o = _prm(V, O, 0, nfeatures=2000, fast_threshold=7)
     O.lib().orc_set_variant(0, 0)
     ek, ed = O.detect_and_compute(img, o)
-    for poison in ("0", "255", "90"):
-        monkeypatch.setenv("VSLAM_AMD_POISON", poison)
+    for poison in (0, 255, 90):
         c = V.Context(device=0, max_w=1024, max_h=1024, max_batch=2)
+        c._check(c.lib.mo_dbg_set_poison(c.h, poison))
         try:
             for _ in range(2):
                 (k, d), = c.orb_detect_compute(img, p)
@@ -248,38 +252,26 @@ def test_skipped_level_margins_never_reach_a_result(O, size, monkeypatch):
     O.lib().orc_set_variant(1, 0)
 
 
-def test_aux_stream_blur_optin_same_results(monkeypatch):
-    """The blur runs in line by default; VSLAM_AMD_SERIAL_BLUR=0 forks it onto an auxiliary stream beside FAST + selection.
-    Results are the same either way, and the in-line form reports the blur as a stage of its own."""
-    import vslam_amd as V
-    p = V.orb_params(nfeatures=500)
-    img = synthetic_frame(11)
-    c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
-    (k1, d1), = c.orb_detect_compute(img, p)
-    assert [n for n, _ in c.stage_times()] == ["pyramid", "blur", "fast_nms", "select_harris", "angle_rbrief"]
-    c.close()
-    monkeypatch.setenv("VSLAM_AMD_SERIAL_BLUR", "0")
-    c = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
-    (k2, d2), = c.orb_detect_compute(img, p)
-    assert [n for n, _ in c.stage_times()] == ["pyramid", "fast_nms", "select_harris", "blur", "angle_rbrief"]
-    assert np.array_equal(k1, k2) and np.array_equal(d1, d2)
-    c.close()
-
-
 def test_stage_times_ring(ctx):
     """mo_stage_times_back: one event set per call, readable after later calls (bench.py reads a whole timed region after ONE sync)."""
     import vslam_amd as V
     p = V.orb_params(nfeatures=500)
     img = synthetic_frame(7)
     ctx.orb_detect_compute(img, p)
-    ctx.match_knn2_ratio(np.zeros((4, 32), np.uint8), np.zeros((5, 32), np.uint8), 0.75)
-    last, before = ctx.stage_times(0), ctx.stage_times(1)
-    assert [n for n, _ in last] == ["match_knn2_ratio"]
-    assert [n for n, _ in before] == ["pyramid", "blur", "fast_nms", "select_harris", "angle_rbrief"]
-    assert all(ms >= 0.0 for _, ms in last + before)
-    assert ctx.stage_times() == last
-    with pytest.raises(V.NativeError):
-        ctx.stage_times(V.TIMING_SLOTS)
+    assert ctx.stage_times() == []          # the single-call host entry points record no events unless asked to (mo_set_host_timing)
+    ctx.set_host_timing(True)
+    try:
+        ctx.orb_detect_compute(img, p)
+        ctx.match_knn2_ratio(np.zeros((4, 32), np.uint8), np.zeros((5, 32), np.uint8), 0.75)
+        last, before = ctx.stage_times(0), ctx.stage_times(1)
+        assert [n for n, _ in last] == ["h2d", "match_knn2_ratio", "d2h"]
+        assert [n for n, _ in before] == ["h2d", "pyramid", "blur", "fast_nms", "select_harris", "angle_rbrief", "d2h"]
+        assert all(ms >= 0.0 for _, ms in last + before)
+        assert ctx.stage_times() == last
+        with pytest.raises(V.NativeError):
+            ctx.stage_times(V.TIMING_SLOTS)
+    finally:
+        ctx.set_host_timing(False)
 
 
 def test_compute_given_keypoints(ctx, O):

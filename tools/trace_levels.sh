@@ -6,7 +6,7 @@ K=${1:-k_resize2}
 O=$R/gpurun_out/trace_levels
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-VSLAM_AMD_SERIAL_BLUR=1 rocprofv3 --kernel-trace -d $O -o t --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optin --no-extras > /dev/null 2> $O/err.txt
+rocprofv3 --kernel-trace -d $O -o t --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-optin --no-extras > /dev/null 2> $O/err.txt
 python3 - "$O" "$K" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]

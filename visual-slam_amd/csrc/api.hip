@@ -11,7 +11,19 @@
 // Flag words: kernels raise bits in c->flags_cur[0].  mo_dev_* calls point it at words 0..3 (accumulated until mo_dev_status reads
 // and clears them); host entry points point it at words 4..7, which they clear before and check after their own kernels - a host
 // call between mo_dev_frontend_batch and mo_dev_status neither erases nor inherits the pending device-call bits.
-static inline int* host_flags(mo_ctx* c) { return c->d_flags + 4; }
+static inline int* host_flags(mo_ctx* c) { return mo_host_flags(c); }
+
+extern "C" int mo_set_host_timing(mo_ctx* c, int on) {
+    if (!c) return MO_ERR_ARG;
+    c->host_timing = on != 0;
+    return MO_OK;
+}
+
+extern "C" int mo_host_times(mo_ctx* c, double us[4]) {
+    if (!c || !us) return MO_ERR_ARG;
+    for (int i = 0; i < 4; i++) us[i] = c->host_us[i];
+    return MO_OK;
+}
 
 static bool grow_fin_slots(mo_ctx* c);
 
@@ -38,52 +50,34 @@ extern "C" int mo_dev_status(mo_ctx* c, int32_t flags[4]) {
 }
 
 // device pipeline on frames already resident as dense gray [batch][h][w]
-static int run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int w, int h, int batch,
-                       mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts, bool host_call) {
+int mo_run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int w, int h, int batch,
+                   mo_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_counts, int host_call) {
     int rc = mo_build_plan(c, p, w, h, batch);
     if (rc) return rc;
     if (cap < 1) return mo_fail(c, MO_ERR_ARG, "cap must be >= 1");
     // host calls check their own flag words before they return; mo_dev_* calls accumulate theirs until mo_dev_status
     c->flags_cur = host_call ? host_flags(c) : c->d_flags;
-    if (host_call) HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));
-    if (c->poison >= 0) {  // VSLAM_AMD_POISON=<byte> (tests): whatever the margins skip must never reach a result
+    if (host_call == 1) HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));  // (2: the upload kernel cleared them)
+    if (c->poison >= 0) {  // mo_dbg_set_poison (tests): whatever the margins skip must never reach a result
         HIPCHK(c, hipMemsetAsync(c->d_pyr, c->poison, (size_t)c->batch_alloc * c->plan.pyr_stride, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_blur, c->poison, (size_t)c->batch_alloc * c->plan.blur_stride, c->stream));
     }
-    mo_stage_begin(c);
+    if (host_call) mo_stage_mark(c, "h2d");  // (the host call opened its event set before the upload)
+    else mo_stage_begin(c);
     // margins of the levels nothing in this pipeline reads (see orb_launch_blur / orb_launch_pyramid)
-    const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
+    const int blur_margin = (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
     if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels, pyr_margin))) return rc;
     mo_stage_mark(c, "pyramid");
-    // The Gaussian blur only depends on the pyramid.  Default: in line, right behind the pyramid.  VSLAM_AMD_SERIAL_BLUR=0 (opt-in)
-    // forks it onto the auxiliary stream beside FAST + selection; measured (profiles/r02_ab_serial_blur.txt) that form gains <= 1 %
-    // and only when the runtime happens to map the two streams onto different hardware queues.
-    const bool aux_blur = d_desc && !c->serial_blur && c->aux_stream;
-    if (d_desc && !aux_blur) {
+    // the Gaussian blur only depends on the pyramid: in line, right behind it (an aux-stream fork beside FAST + selection gained <= 1 %
+    // in rounds 1 - 2 and was retired: profiles/r02_ab_serial_blur.txt)
+    if (d_desc) {
         if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin))) return rc;
         mo_stage_mark(c, "blur");
-    }
-    if (aux_blur) {
-        hipStream_t main_s = c->stream;
-        HIPCHK(c, hipEventRecord(c->ev_fork, main_s));
-        HIPCHK(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-        c->stream = c->aux_stream;
-        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux0, c->aux_stream);
-        rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin);
-        if (c->timing) hipEventRecord(c->tsets[c->tcur].aux1, c->aux_stream);
-        hipEventRecord(c->ev_join, c->aux_stream);
-        c->stream = main_s;
-        if (rc) return rc;
     }
     if ((rc = orb_launch_fast(c, d_gray, batch))) return rc;
     mo_stage_mark(c, "fast_nms");
     if ((rc = orb_launch_select(c, d_gray, batch))) return rc;
     mo_stage_mark(c, "select_harris");
-    if (aux_blur) {
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        mo_stage_mark(c, "blur");  // time taken from the aux-stream events; on the main stream this is only the join
-        c->tsets[c->tcur].aux_stage = c->tsets[c->tcur].n_stages - 1;
-    }
     if ((rc = orb_launch_describe(c, d_gray, batch, d_kps, d_desc, cap, d_counts))) return rc;
     mo_stage_mark(c, "angle_rbrief");
     return MO_OK;
@@ -117,7 +111,7 @@ static int run_grid_extract(mo_ctx* c, const mo_orb_params* p, const mo_batch_io
     int32_t* d_kb = (int32_t*)(b + o_kb);
     if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, io->d_kps, io->d_grid_kept, cap, io->d_counts, batch, d_kb))) return rc;
     mo_stage_mark(c, "grid_good_features");
-    const int blur_margin = c->blur_full ? 0 : (c->plan.edge_threshold - 19) & ~3;
+    const int blur_margin = (c->plan.edge_threshold - 19) & ~3;
     if ((rc = orb_launch_blur(c, io->d_gray, batch, 1, blur_margin))) return rc;  // the records all sit on octave 0
     mo_stage_mark(c, "blur");
     // descriptors out of one blurred LDS tile per grid cell; cells too large for the tile (frames beyond ~ 720 x 480) take the
@@ -166,15 +160,17 @@ static int reserve_out(mo_ctx* c, int batch, int cap) {
     return MO_OK;
 }
 
-// pinned host staging owned by the context (small host-API transfers: one async copy each way and one synchronisation instead of
-// a blocking round trip per pageable array)
-static int host_stage(mo_ctx* c, size_t bytes) {
+// pinned host staging owned by the context (small host-API transfers: one copy each way and one synchronisation instead of a blocking
+// round trip per pageable array).  Mapped + coherent: k_ingest / k_pack_out read and write it from the device.
+int mo_host_stage(mo_ctx* c, size_t bytes) {
     if (c->h_stage_bytes >= bytes) return MO_OK;
     if (c->h_stage) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_bytes = 0; }
-    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocDefault));
+    bytes = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    HIPCHK(c, hipHostMalloc((void**)&c->h_stage, bytes, hipHostMallocMapped | hipHostMallocCoherent));
     c->h_stage_bytes = bytes;
     return MO_OK;
 }
+static int host_stage(mo_ctx* c, size_t bytes) { return mo_host_stage(c, bytes); }
 
 // true when a level's final-keypoint slot can still grow (then the plan is invalidated so that the next call rebuilds it larger).
 // retainBest keeps EVERY element that ties with the quota boundary, so a level of a periodic synthetic pattern can keep all its
@@ -205,12 +201,16 @@ extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const ui
 static int detect_compute_once(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
                                int batch, mo_keypoint* kps, uint8_t* desc, int cap, int* counts) {
     HIPCHK(c, hipSetDevice(c->device));
+    // one frame (the drop-in classes, a Tracker): pinned staging both ways, a resident result slot, one synchronisation (frame_api.hip)
+    if (batch == 1 && (size_t)w * h * ch + (size_t)cap * 60 <= (size_t)64 << 20) return mo_detect_single(c, p, img, w, h, stride, ch, kps, desc, cap, counts);
+    HostClock clk(c);
     const uint8_t* d_gray = nullptr;
     int rc = mo_build_plan(c, p, w, h, batch);  // validates sizes before any staging
     if (rc) return rc;
+    mo_stage_begin(c);
     if ((rc = stage_images(c, img, w, h, stride, ch, batch, &d_gray))) return rc;
     if ((rc = reserve_out(c, batch, cap))) return rc;
-    if ((rc = run_extract(c, p, d_gray, w, h, batch, c->d_kps, desc ? c->d_desc : nullptr, cap, c->d_counts, true))) return rc;
+    if ((rc = mo_run_extract(c, p, d_gray, w, h, batch, c->d_kps, desc ? c->d_desc : nullptr, cap, c->d_counts, true))) return rc;
     // Small results (the single-frame calls of the drop-in classes): flags, counts, keypoints and descriptors travel into ONE pinned
     // staging buffer behind one synchronisation; copies into the caller's pageable arrays cost a blocking round trip each (four
     // per call before: counts, flags, keypoints, descriptors).
@@ -223,7 +223,10 @@ static int detect_compute_once(mo_ctx* c, const mo_orb_params* p, const uint8_t*
         HIPCHK(c, hipMemcpyAsync(hs + o_cnt, c->d_counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(hs + o_kps, c->d_kps, n_rows * sizeof(mo_keypoint), hipMemcpyDeviceToHost, c->stream));
         if (desc) HIPCHK(c, hipMemcpyAsync(hs + o_desc, c->d_desc, n_rows * 32, hipMemcpyDeviceToHost, c->stream));
+        mo_stage_mark(c, "d2h");
+        clk.enqueued();
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        clk.waited();
         std::memcpy(counts, hs + o_cnt, (size_t)batch * sizeof(int));  // MO_ERR_CAPACITY: counts already holds the sizes a retry needs
         const int fl = ((const int*)hs)[0];
         if (fl & 1) { c->tie_overflow = true; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
@@ -446,6 +449,12 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     return MO_OK;
 }
 
+extern "C" int mo_dbg_set_poison(mo_ctx* c, int byte) {
+    if (!c) return MO_ERR_ARG;
+    c->poison = byte < 0 ? -1 : (byte & 255);
+    return MO_OK;
+}
+
 extern "C" int mo_dbg_min_eigen(mo_ctx* c, const uint8_t* gray, int w, int h, float* eig) {
     if (!c) return MO_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -459,6 +468,7 @@ extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const ui
     if (nq == 0) return MO_OK;
     if (!q || !train_idx || !dist || !pass || (nt > 0 && !t)) return mo_fail(c, MO_ERR_ARG, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
+    HostClock clk(c);
     size_t qb = (size_t)batch * nq * 32, tb = (size_t)batch * std::max(nt, 1) * 32, n = (size_t)batch * nq;
     int rc;
     if ((rc = mo_reserve(c, c->d_mq, c->m_q_bytes, qb))) return rc;
@@ -481,13 +491,15 @@ extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const ui
         HIPCHK(c, hipStreamSynchronize(c->stream));  // (the staging buffer of a previous call has been consumed)
         std::memcpy(c->h_stage, q, qb);
         if (nt > 0) std::memcpy(c->h_stage + o_t, t, tbytes);
+        mo_stage_begin(c);
         HIPCHK(c, hipMemcpyAsync(c->d_mq, c->h_stage, qb, hipMemcpyHostToDevice, c->stream));
         if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, c->h_stage + o_t, tbytes, hipMemcpyHostToDevice, c->stream));
     } else {
+        mo_stage_begin(c);
         HIPCHK(c, hipMemcpyAsync(c->d_mq, q, qb, hipMemcpyHostToDevice, c->stream));
         if (nt > 0) HIPCHK(c, hipMemcpyAsync(c->d_mt, t, tbytes, hipMemcpyHostToDevice, c->stream));
     }
-    mo_stage_begin(c);
+    mo_stage_mark(c, "h2d");
     rc = match_launch_pairs(c, c->d_mq, c->d_mt, (size_t)nq * 32, (size_t)nt * 32, nullptr, nullptr, nullptr, nq, nt, batch,
                             nq, ratio ? *ratio : -1.0, c->d_midx, c->d_mdist, c->d_mpass);
     if (rc) return rc;
@@ -496,7 +508,10 @@ extern "C" int mo_match_knn2_ratio(mo_ctx* c, const uint8_t* q, int nq, const ui
         HIPCHK(c, hipMemcpyAsync(c->h_stage + o_idx, c->d_midx, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_stage + o_dist, c->d_mdist, n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_stage + o_pass, c->d_mpass, n, hipMemcpyDeviceToHost, c->stream));
+        mo_stage_mark(c, "d2h");
+        clk.enqueued();
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        clk.waited();
         std::memcpy(train_idx, c->h_stage + o_idx, n * 2 * sizeof(int32_t));
         std::memcpy(dist, c->h_stage + o_dist, n * 2 * sizeof(int32_t));
         std::memcpy(pass, c->h_stage + o_pass, n);
@@ -515,7 +530,7 @@ extern "C" int mo_init_two_view(mo_ctx* c, const float* p1, const float* p2, int
     (void)prob;
     if (!c) return MO_ERR_ARG;
     if (!p1 || !p2 || !K || !R || !t || !inlier || !X || !n_good) return mo_fail(c, MO_ERR_ARG, "NULL argument");
-    if (m < 0 || m > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "m must be 0..4096");
+    if (m < 0) return mo_fail(c, MO_ERR_ARG, "m must be >= 0");
     HIPCHK(c, hipSetDevice(c->device));
     *n_good = 0;
     if (m < 8) {
@@ -571,7 +586,6 @@ extern "C" int mo_recover_pose(mo_ctx* c, const double E[9], const float* p1, co
                                const uint8_t* mask_in, double R[9], double t[3], uint8_t* mask_out, float* X, int* n_good) {
     if (!c) return MO_ERR_ARG;
     if (!E || !K || !R || !t || !n_good || m < 0 || (m > 0 && (!p1 || !p2 || !mask_out))) return mo_fail(c, MO_ERR_ARG, "NULL / negative argument");
-    if (m > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "m must be 0..4096");
     HIPCHK(c, hipSetDevice(c->device));
     *n_good = 0;
     for (int i = 0; i < 9; i++) R[i] = NAN;
@@ -618,7 +632,6 @@ extern "C" int mo_find_fundamental(mo_ctx* c, const float* p1, const float* p2, 
     (void)prob;
     if (!c) return MO_ERR_ARG;
     if (!F || !n_inliers || m < 0 || (m > 0 && (!p1 || !p2 || !mask))) return mo_fail(c, MO_ERR_ARG, "NULL / negative argument");
-    if (m > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "m must be 0..4096");
     HIPCHK(c, hipSetDevice(c->device));
     *n_inliers = 0;
     for (int i = 0; i < 9; i++) F[i] = NAN;
@@ -658,80 +671,25 @@ extern "C" int mo_track_pair(mo_ctx* c, const mo_keypoint* kps1, int n1, const u
                              int* n_sel, uint8_t* inlier, int* n_inliers) {
     if (!c) return MO_ERR_ARG;
     if (!K || !R || !t || !n_sel || !n_inliers || n1 < 0 || n2 < 0) return mo_fail(c, MO_ERR_ARG, "NULL / negative argument");
-    if (n1 > 4096 || n2 > 4096) return mo_fail(c, MO_ERR_UNSUPPORTED, "at most 4096 keypoints per frame");
-    HIPCHK(c, hipSetDevice(c->device));
     *n_sel = 0; *n_inliers = 0;
     for (int i = 0; i < 9; i++) { R[i] = NAN; if (E) E[i] = NAN; }
     for (int i = 0; i < 3; i++) t[i] = NAN;
     if (n1 == 0 || n2 == 0) return MO_OK;
     if (!kps1 || !kps2 || !desc1 || !desc2 || !sel_idx || !inlier) return mo_fail(c, MO_ERR_ARG, "NULL argument");
-    const int cap = (std::max(n1, n2) + 15) & ~15;
-    // device layout of a two-frame batch: [kps 2 x cap][desc 2 x cap x 32][counts 2][match idx / dist / pass][sel ...][two-view outputs]
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    // (inputs first and contiguous, outputs contiguous: ONE copy each way through the pinned staging buffer, which mirrors the layout)
-    const size_t o_kps = take((size_t)2 * cap * sizeof(mo_keypoint)), o_desc = take((size_t)2 * cap * 32), o_cnt = take(2 * sizeof(int32_t)),
-                 o_qt = take(2 * sizeof(int32_t)), in_end = off,
-                 o_midx = take((size_t)cap * 2 * sizeof(int32_t)), o_mdist = take((size_t)cap * 2 * sizeof(int32_t)), o_mpass = take(cap),
-                 o_sel = take((size_t)cap * 2 * sizeof(int32_t)), o_seld = take((size_t)cap * sizeof(int32_t)), o_seln = take(sizeof(int32_t)),
-                 o_pose = take(12 * sizeof(double)), o_E = take(9 * sizeof(double)), o_inl = take(cap), o_np = take(sizeof(int32_t)),
-                 out_end = off, o_X = take((size_t)cap * 3 * sizeof(float));
-    int rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, off);
+    // the host-array form of mo_pair_frontend(MO_MODE_TRACK) (frame_api.hip): both frames are uploaded into resident slots
+    mo_frame_ref f1 = {0, kps1, desc1, n1}, f2 = {0, kps2, desc2, n2};
+    mo_pair_params pp;
+    std::memset(&pp, 0, sizeof(pp));
+    pp.mode = MO_MODE_TRACK; pp.w = w; pp.h = h; pp.ratio = ratio; pp.disp_frac = disp_frac; pp.thr_px = thr_px; pp.n_hyp = n_hyp; pp.seed = seed;
+    for (int i = 0; i < 9; i++) pp.K[i] = K[i];
+    mo_pair_out o;
+    std::memset(&o, 0, sizeof(o));
+    o.sel_idx = sel_idx; o.sel_dist = sel_dist; o.inlier = inlier;
+    const int rc = mo_pair_frontend(c, &f1, &f2, &pp, &o);
     if (rc) return rc;
-    if ((rc = host_stage(c, out_end))) return rc;
-    uint8_t* b = (uint8_t*)c->d_tmp;
-    uint8_t* hs = c->h_stage;
-    mo_keypoint* d_kps = (mo_keypoint*)(b + o_kps);
-    uint8_t* d_desc = b + o_desc;
-    int32_t* d_cnt = (int32_t*)(b + o_cnt);
-    int32_t* d_qt = (int32_t*)(b + o_qt);  // pair 0 = frame 0 (query) vs frame 1 (train)
-    const int32_t cnt[2] = {n1, n2}, qt[2] = {0, 1};
-    std::memcpy(hs + o_kps, kps1, (size_t)n1 * sizeof(mo_keypoint));
-    std::memcpy(hs + o_kps + (size_t)cap * sizeof(mo_keypoint), kps2, (size_t)n2 * sizeof(mo_keypoint));
-    std::memcpy(hs + o_desc, desc1, (size_t)n1 * 32);
-    std::memcpy(hs + o_desc + (size_t)cap * 32, desc2, (size_t)n2 * 32);
-    std::memcpy(hs + o_cnt, cnt, sizeof(cnt));
-    std::memcpy(hs + o_qt, qt, sizeof(qt));
-    HIPCHK(c, hipMemcpyAsync(b, hs, in_end, hipMemcpyHostToDevice, c->stream));
-    mo_stage_begin(c);
-    if ((rc = match_launch_pairs(c, d_desc, d_desc, (size_t)cap * 32, (size_t)cap * 32, d_cnt, d_qt, d_qt + 1, 0, 0, 1, cap, ratio,
-                                 (int32_t*)(b + o_midx), (int32_t*)(b + o_mdist), b + o_mpass)))
-        return rc;
-    if ((rc = track_select_launch(c, d_kps, d_cnt, d_qt, d_qt + 1, (int32_t*)(b + o_midx), (int32_t*)(b + o_mdist), b + o_mpass, cap, 1,
-                                  w, h, disp_frac, (int32_t*)(b + o_sel), (int32_t*)(b + o_seld), (int32_t*)(b + o_seln))))
-        return rc;
-    TwoViewArgs a;
-    std::memset(&a, 0, sizeof(a));
-    a.n_pairs = 1; a.cap = cap; a.n_hyp = n_hyp;
-    for (int i = 0; i < 9; i++) a.K[i] = K[i];
-    a.thr_px = thr_px; a.seed = seed;
-    a.d_kps = d_kps; a.d_counts = d_cnt; a.d_match_idx = (int32_t*)(b + o_midx); a.d_match_pass = b + o_mpass;
-    a.d_sel = (int32_t*)(b + o_sel); a.d_sel_n = (int32_t*)(b + o_seln);
-    a.d_pose = (double*)(b + o_pose); a.d_E = (double*)(b + o_E); a.d_points = (float*)(b + o_X); a.d_inlier = b + o_inl;
-    a.d_n_points = (int32_t*)(b + o_np);
-    if ((rc = twoview_launch(c, a))) return rc;
-    mo_stage_mark(c, "track_pair");
-    HIPCHK(c, hipMemcpyAsync(hs + o_sel, b + o_sel, out_end - o_sel, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    int32_t ns = *(const int32_t*)(hs + o_seln);
-    const int32_t np = *(const int32_t*)(hs + o_np);
-    const double* pose = (const double*)(hs + o_pose);
-    const double* Eh = (const double*)(hs + o_E);
-    ns = std::min(std::max(ns, 0), cap);
-    *n_sel = ns;
-    if (ns > 0) {
-        std::memcpy(sel_idx, hs + o_sel, (size_t)ns * 2 * sizeof(int32_t));
-        if (sel_dist) std::memcpy(sel_dist, hs + o_seld, (size_t)ns * sizeof(int32_t));
-        const uint8_t* mask = hs + o_inl;
-        for (int j = 0; j < ns; j++) inlier[j] = mask[(size_t)sel_idx[2 * j]];  // the pose mask is indexed by query keypoint
-    }
-    if (ns >= 8) {  // tracker.py:234: fewer than 8 matches -> tracking fails (R, t stay NaN)
-        for (int i = 0; i < 9; i++) { R[i] = pose[i]; if (E) E[i] = Eh[i]; }
-        for (int i = 0; i < 3; i++) t[i] = pose[9 + i];
-        *n_inliers = np;
-    } else {
-        std::memset(inlier, 0, (size_t)ns);
-    }
+    *n_sel = o.n_sel; *n_inliers = o.n_good;
+    for (int i = 0; i < 9; i++) { R[i] = o.R[i]; if (E) E[i] = o.E[i]; }
+    for (int i = 0; i < 3; i++) t[i] = o.t[i];
     return MO_OK;
 }
 
@@ -761,7 +719,7 @@ extern "C" int mo_dev_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, cons
     if (!c) return MO_ERR_ARG;
     if (!d_gray || !d_kps || !d_counts) return mo_fail(c, MO_ERR_ARG, "NULL device pointer");
     HIPCHK(c, hipSetDevice(c->device));
-    return run_extract(c, p, d_gray, w, h, batch, d_kps, d_desc, cap, d_counts, false);
+    return mo_run_extract(c, p, d_gray, w, h, batch, d_kps, d_desc, cap, d_counts, false);
 }
 
 extern "C" int mo_dev_match_pairs(mo_ctx* c, const uint8_t* d_desc, const int32_t* d_counts, int cap, const int32_t* d_qf,
@@ -788,7 +746,7 @@ extern "C" int mo_dev_frontend_batch(mo_ctx* c, const mo_orb_params* p, const mo
     HIPCHK(c, hipSetDevice(c->device));
     if (io->detector != MO_DETECT_ORB && io->detector != MO_DETECT_GRID) return mo_fail(c, MO_ERR_ARG, "mo_batch_io.detector must be MO_DETECT_ORB or MO_DETECT_GRID");
     int rc = io->detector == MO_DETECT_GRID ? run_grid_extract(c, p, io)
-                                            : run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, false);
+                                            : mo_run_extract(c, p, io->d_gray, io->w, io->h, io->batch, io->d_kps, io->d_desc, io->cap, io->d_counts, false);
     if (rc) return rc;
     if (io->mode == MO_MODE_KEYFRAME) {
         // LocalMapper._process_new_keyframe (local_mapper.py:116-149) for n_kf_pairs (query keyframe, train keyframe) pairs of the batch

@@ -1,6 +1,7 @@
 // common.h -- context, plan and helpers shared by the HIP translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -56,30 +57,23 @@ struct ResizeTab {  // device arrays of one level's INTER_LINEAR_EXACT coefficie
     bool two_pass_ok = true;  // k_resize2's 8-byte source window holds every group of 4 output columns
 };
 
+#define MO_RESULT_SLOTS 4
 #define MO_NSTAGES 16
 #define MO_TIMING_SLOTS 64
 
 struct TimingSet {
     hipEvent_t ev[MO_NSTAGES + 1] = {};
-    hipEvent_t aux0 = nullptr, aux1 = nullptr;  // span of the stage that ran on the aux stream
     const char* names[MO_NSTAGES + 1] = {};
-    int n_stages = 0, aux_stage = -1;            // aux_stage: stage slot whose time comes from (aux0, aux1)
+    int n_stages = 0;
 };
 
 struct mo_ctx {
     int device = 0;
     int max_w = 0, max_h = 0, max_batch = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
-    int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in
-                               // matrix-core matcher, 2 "scalar" round-1 kernel (train descriptors through scalar loads)
-    bool resize_gather = false;  // VSLAM_AMD_RESIZE=gather: the round-1 LDS-gather resize kernel for every level (A/B timing)
-    int strip_rows = MO_STRIP_ROWS;  // rows per FAST strip (VSLAM_AMD_STRIP_ROWS: A/B timing)
-    int poison = -1;             // VSLAM_AMD_POISON=<0..255>: fill the pyramid buffers with that byte before every extraction (tests)
-    bool blur_full = false;      // VSLAM_AMD_BLUR=full: the pipeline blurs whole levels (A/B timing)
-    bool serial_blur = true;   // the blur runs in line on the context stream (default).  VSLAM_AMD_SERIAL_BLUR=0 opts into the
-                               // aux-stream fork / join of rounds 1 - 2 (measured gain <= 1 %, and only where the runtime maps the
-                               // two streams onto different hardware queues)
-    hipStream_t aux_stream = nullptr;           // opt-in: runs the blur beside FAST + selection (both only depend on the pyramid)
+    int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in matrix-core matcher
+    int poison = -1;           // mo_dbg_set_poison (tests): fill the pyramid buffers with that byte before every extraction
+    hipStream_t aux_stream = nullptr;           // single-frame extraction: the coarse levels' chain beside the finest level's (frame_api.hip)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
@@ -113,14 +107,23 @@ struct mo_ctx {
                                    // mo_dev_status), words 4..7 to the host entry points (cleared and checked inside each call)
     int* flags_cur = nullptr;      // the word block the kernels of the current call raise their bits in
     unsigned lds_attr_done = 0;    // bit per kernel whose max-dynamic-LDS attribute has been raised on this device
-    // output staging for the host API
+    // output staging for the host API (batches of frames)
     mo_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int* d_counts = nullptr; int out_cap = 0, out_batch = 0;
+    // Resident results of the last MO_RESULT_SLOTS single-frame extractions of the host API: slot s is "frame s" of these arrays, so the
+    // pair stages (matcher, tracking filters, two-view) run on two slots exactly as they run on two frames of a batch, and a Tracker-style
+    // caller that hands a frame's token back (mo_pair_frontend) uploads nothing.
+    mo_keypoint* d_slot_kps = nullptr; uint8_t* d_slot_desc = nullptr; int32_t* d_slot_cnt = nullptr; int32_t* d_slot_ids = nullptr;
+    int slot_cap = 0, slot_cur = -1;
+    uint64_t slot_token[MO_RESULT_SLOTS] = {}; int slot_n[MO_RESULT_SLOTS] = {}; uint64_t token_next = 1, last_token = 0;
+    bool host_timing = false;      // stage events inside the single-call host entry points (mo_set_host_timing; an event between two
+                                   // kernels idles the GPU for ~ 4.5 us, five of them were 9 % of a single-frame extraction)
     // matcher staging
     uint8_t* d_mq = nullptr; uint8_t* d_mt = nullptr; int32_t* d_midx = nullptr; int32_t* d_mdist = nullptr;
     uint8_t* d_mpass = nullptr; size_t m_q_bytes = 0, m_t_bytes = 0, m_n = 0;
     uint2* d_match_part = nullptr; size_t match_part_bytes = 0;  // per-slice keys of a split k_match_lds launch
     // two-view work buffers
     void* d_tv = nullptr; size_t tv_bytes = 0;
+    uint32_t* d_track_keys = nullptr; size_t track_keys_bytes = 0;  // k_track_select: key arrays of frames too large for LDS
     // generic temp
     void* d_tmp = nullptr; size_t tmp_bytes = 0;
 
@@ -128,6 +131,7 @@ struct mo_ctx {
     void* comm = nullptr; int comm_rank = 0, comm_world = 1;
     int32_t* d_comm_cnt = nullptr;  // this rank's row count for mo_gather_map_points' all-gather
 
+    double host_us[4] = {0, 0, 0, 0};  // mo_host_times: enqueue / wait / unpack / total of the last single-call host entry point
     uint8_t* h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned host staging of small host-API results
     int32_t* d_pair_frames = nullptr; int pair_frames_n = 0, pair_frames_split = 0;  // mo_dev_frontend_batch: qf[i] = i, tf[i] = i + 1
     // stage timing: a ring of event sets, one per mo_* call (mo_stage_begin advances it), so that a caller can enqueue many calls
@@ -156,6 +160,35 @@ template <class T> int mo_reserve(mo_ctx* c, T*& p, size_t& have_bytes, size_t n
     return MO_OK;
 }
 
+// pinned, device-mapped host staging of the single-call host entry points (grow-only)
+int mo_host_stage(mo_ctx* c, size_t bytes);
+// flag words of the host entry points (see api.hip)
+static inline int* mo_host_flags(mo_ctx* c) { return c->d_flags + 4; }
+
+// Host-side clock of the single-call entry points (mo_host_times): [0] entry -> everything enqueued (staging memcpy, copies, launches),
+// [1] the wait for the stream, [2] unpacking into the caller's arrays, [3] the whole call; microseconds.
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct HostClock {
+    mo_ctx* c; double t0, t1 = 0, t2 = 0;
+    explicit HostClock(mo_ctx* c_) : c(c_), t0(now_us()) { c->timing = c->host_timing; }
+    void enqueued() { t1 = now_us(); }
+    void waited() { t2 = now_us(); }
+    ~HostClock() {
+        const double t3 = now_us();
+        if (t1 == 0) t1 = t2 = t3; else if (t2 == 0) t2 = t3;
+        c->host_us[0] = t1 - t0; c->host_us[1] = t2 - t1; c->host_us[2] = t3 - t2; c->host_us[3] = t3 - t0;
+        c->timing = true;  // (the mo_dev_* calls always record their stage events: bench.py reads them)
+    }
+};
+
+// device pipeline on frames already resident as dense gray [batch][h][w] (api.hip); host_call != 0: the caller opened the stage set and
+// the kernels raise their bits in the host flag words (1: cleared here by a fill, 2: already cleared by the upload kernel)
+int mo_run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int w, int h, int batch, mo_keypoint* d_kps, uint8_t* d_desc,
+                   int cap, int32_t* d_counts, int host_call);
+// frame_api.hip: single-frame extraction into a resident result slot (pinned staging in and out, one synchronisation)
+int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch, mo_keypoint* kps,
+                     uint8_t* desc, int cap, int* counts);
+
 // stage timing helpers (hipEvents on the context stream)
 void mo_stage_begin(mo_ctx* c);
 void mo_stage_mark(mo_ctx* c, const char* name);
@@ -165,6 +198,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch);
 
 // kernel launchers (orb_kernels.hip)
 int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray);
+int orb_launch_ingest(mo_ctx* c, const uint8_t* src_mapped, int w, int h, int ch, uint8_t* d_gray, int* flags_clear);
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
 int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
 int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
@@ -211,9 +245,8 @@ struct TwoViewArgs {
     uint8_t* d_inlier; // [pairs][cap] pose mask
     uint8_t* d_ransac; // [pairs][cap] RANSAC (Sampson) mask or null
     int32_t* d_n_points; // [pairs]
-    int* flags;          // capacity flag word (bit 3: a pair with more than TV_MAX_M correspondences gets no model); set by twoview_launch
+    int* flags;          // capacity flag word (none raised by this stage any more); set by twoview_launch
 };
-#define TV_MAX_M 4096     // correspondences of one pair the two-view stage takes (sampler arithmetic, per-thread consensus bits)
 int twoview_launch(mo_ctx* c, const TwoViewArgs& a);
 // undistort_kernels.hip
 int undistort_launch(mo_ctx* c, const uint8_t* d_src, uint8_t* d_dst, int w, int h, int ch, int batch, const double K[9],

@@ -55,30 +55,17 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
         return nullptr;
     }
     c->stream = c->own_stream;
-    if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : std::strcmp(e, "scalar") == 0 ? 2 : 0;
-    if (const char* e = getenv("VSLAM_AMD_SERIAL_BLUR")) c->serial_blur = e[0] != '0';
-    if (!c->serial_blur) {  // opt-in: the auxiliary stream only fills idle CUs: lowest priority, so FAST + selection on the main stream keep theirs
-        int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&c->aux_stream, hipStreamNonBlocking, lo) != hipSuccess &&
-            hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess)
-            c->serial_blur = true;
-    }
-    if (const char* e = getenv("VSLAM_AMD_RESIZE")) c->resize_gather = e[0] == 'g';
-    if (const char* e = getenv("VSLAM_AMD_BLUR")) c->blur_full = e[0] == 'f';
-    if (const char* e = getenv("VSLAM_AMD_POISON")) c->poison = atoi(e) & 255;
-    if (const char* e = getenv("VSLAM_AMD_STRIP_ROWS")) c->strip_rows = std::min(std::max(atoi(e), 2), 16);
+    // the one environment switch of the library: VSLAM_AMD_MATCHER=mfma selects the opt-in matrix-core matcher (identical results;
+    // north_star prescribes XOR + popcount as the default, bench.py times the opt-in beside it)
+    if (const char* e = getenv("VSLAM_AMD_MATCHER")) c->match_mode = std::strcmp(e, "mfma") == 0 ? 1 : 0;
     // hipEventDisableSystemFence: these events order work of ONE device (kernel boundaries already release / acquire at agent
     // scope); the default system-scope fence of an event record writes the L2 back and cost 6 - 17 us of idle GPU at every stage mark
-    // (kernel trace: gaps only where an event sits between two kernels), 0.06 ms of a 2.2 ms step.  VSLAM_AMD_EVENT_FENCE=1 restores it.
-    const unsigned evf = getenv("VSLAM_AMD_EVENT_FENCE") && getenv("VSLAM_AMD_EVENT_FENCE")[0] == '1' ? 0u : (unsigned)hipEventDisableSystemFence;
+    // (kernel trace: gaps only where an event sits between two kernels), 0.06 ms of a 2.2 ms step (profiles/r02_ab_event_fence.txt).
+    const unsigned evf = (unsigned)hipEventDisableSystemFence;
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | evf);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | evf);
-    for (TimingSet& t : c->tsets) {
-        hipEventCreateWithFlags(&t.aux0, evf);
-        hipEventCreateWithFlags(&t.aux1, evf);
+    for (TimingSet& t : c->tsets)
         for (int i = 0; i <= MO_NSTAGES; i++) hipEventCreateWithFlags(&t.ev[i], evf);
-    }
     if (hipMalloc((void**)&c->d_flags, 8 * sizeof(int)) != hipSuccess) {
         g_create_err = "mo_create: hipMalloc failed";
         delete c;
@@ -112,12 +99,12 @@ extern "C" void mo_destroy(mo_ctx* c) {
     mo_comm_destroy(c);
     free_plan_buffers(c);
     void* bufs[] = {c->d_in, c->d_gray, c->d_flags, c->d_kps, c->d_desc, c->d_counts, c->d_mq, c->d_mt,
-                    c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp, c->d_pair_frames, c->d_dtodo, c->d_comm_cnt};
+                    c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp, c->d_pair_frames, c->d_dtodo, c->d_comm_cnt,
+                    c->d_slot_kps, c->d_slot_desc, c->d_slot_cnt, c->d_slot_ids, c->d_track_keys};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (TimingSet& t : c->tsets) {
         for (int i = 0; i <= MO_NSTAGES; i++) if (t.ev[i]) hipEventDestroy(t.ev[i]);
-        if (t.aux0) { hipEventDestroy(t.aux0); hipEventDestroy(t.aux1); }
     }
     if (c->ev_fork) { hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
@@ -151,7 +138,6 @@ void mo_stage_begin(mo_ctx* c) {
     c->tcur = (c->tcur + 1) % MO_TIMING_SLOTS;
     TimingSet& t = c->tsets[c->tcur];
     t.n_stages = 0;
-    t.aux_stage = -1;
     if (c->timing) hipEventRecord(t.ev[0], c->stream);
 }
 
@@ -173,7 +159,6 @@ extern "C" int mo_stage_times_back(mo_ctx* c, int back, const char*** names, flo
     for (int i = 0; i < n; i++) {
         float v = 0;
         hipEventElapsedTime(&v, t.ev[i], t.ev[i + 1]);
-        if (i == t.aux_stage) hipEventElapsedTime(&v, t.aux0, t.aux1);  // stage that ran on the aux stream
         ms[i] = v;
     }
     t.names[t.n_stages] = nullptr;
@@ -304,7 +289,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         if (v.w <= 2 * et || v.h <= 2 * et) { v.bx0 = v.by0 = et; v.bw = v.bh = 0; }
         else { v.bx0 = et; v.by0 = et; v.bw = v.w - 2 * et; v.bh = v.h - 2 * et; }
         v.inv_bw = v.bw > 1 ? 0xFFFFFFFFu / (uint32_t)v.bw + 1u : 0u;
-        v.strip_rows = c->strip_rows;
+        v.strip_rows = MO_STRIP_ROWS;
         while (v.strip_rows > 1 && v.strip_rows * v.bw > 16384) v.strip_rows /= 2;
         if (v.bw > 16384) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide");
         v.nstrips = v.bh > 0 ? (v.bh + v.strip_rows - 1) / v.strip_rows : 0;

@@ -12,9 +12,6 @@
 
 #include "common.h"
 
-#define MQ_THREADS 256
-#define MQ_Q 2            // queries per lane (4 leaves too few workgroups at 2000 queries per pair: measured slower)
-#define MQ_PER_BLOCK (MQ_THREADS * MQ_Q)
 #define KEY_NONE 0xFFFFFFFFu
 
 // one output row: i0/i1 = trainIdx of the best / second-best neighbour (-1: none), d0/d1 their distances
@@ -50,66 +47,15 @@ __device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-__global__ __launch_bounds__(MQ_THREADS) void k_match(const uint8_t* __restrict__ qbase, const uint8_t* __restrict__ tbase,
-                                                      size_t q_stride, size_t t_stride, const int32_t* __restrict__ counts,
-                                                      const int32_t* __restrict__ qf, const int32_t* __restrict__ tf,
-                                                      int nq_fixed, int nt_fixed, int out_stride, double ratio,
-                                                      int32_t* __restrict__ oidx, int32_t* __restrict__ odist,
-                                                      uint8_t* __restrict__ opass) {
-    const int pair = blockIdx.y;
-    const int qfr = qf ? qf[pair] : pair, tfr = tf ? tf[pair] : pair;
-    const int nq = counts ? min(counts[qfr], out_stride) : nq_fixed;
-    const int nt = counts ? min(counts[tfr], out_stride) : nt_fixed;
-    if (blockIdx.x * MQ_PER_BLOCK >= nq) return;
-    const uint32_t* q = (const uint32_t*)(qbase + (size_t)qfr * q_stride);
-    const uint32_t* t = (const uint32_t*)(tbase + (size_t)tfr * t_stride);
-    uint32_t a[MQ_Q][8], k0[MQ_Q], k1[MQ_Q];
-#pragma unroll
-    for (int m = 0; m < MQ_Q; m++) {
-        const int qi = min(blockIdx.x * MQ_PER_BLOCK + m * MQ_THREADS + (int)threadIdx.x, nq - 1);
-#pragma unroll
-        for (int k = 0; k < 8; k++) a[m][k] = q[(size_t)qi * 8 + k];
-        k0[m] = KEY_NONE; k1[m] = KEY_NONE;
-    }
-    auto fold = [&](int j) {
-        const uint32_t* b = t + (size_t)j * 8;  // wave-uniform address -> scalar loads
-        uint32_t d[MQ_Q];
-#pragma unroll
-        for (int m = 0; m < MQ_Q; m++) d[m] = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t bk = b[k];
-#pragma unroll
-            for (int m = 0; m < MQ_Q; m++) d[m] = bcnt_acc(a[m][k] ^ bk, d[m]);
-        }
-#pragma unroll
-        for (int m = 0; m < MQ_Q; m++) {
-            const uint32_t key = (d[m] << 20) | (uint32_t)j;
-            // k0 <= k1: the new second-best is the median of (k0, k1, key), the new best their minimum
-            k1[m] = med3_u32(k0[m], k1[m], key);
-            k0[m] = min(k0[m], key);
-        }
-    };
-    int j = 0;
-    for (; j + 4 <= nt; j += 4) {  // 4 train descriptors (scalar loads) in flight per trip
-        fold(j); fold(j + 1); fold(j + 2); fold(j + 3);
-    }
-    for (; j < nt; j++) fold(j);
-#pragma unroll
-    for (int m = 0; m < MQ_Q; m++) {
-        const int qi = blockIdx.x * MQ_PER_BLOCK + m * MQ_THREADS + threadIdx.x;
-        if (qi < nq) emit_match_key(k0[m], k1[m], ratio, (size_t)pair * out_stride + qi, oidx, odist, opass);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Default path since round 2: the same XOR + popcount + packed-key fold, but the train descriptors are staged through LDS.
 // A workgroup copies tiles of ML_TILE train descriptors (4 KB, one 16-byte load per thread, register-staged and
 // double-buffered so the next tile's global load is in flight during the current tile's compute; one barrier per tile)
 // and every wavefront reads them back with wave-uniform (broadcast) ds_read_b128: two LDS instructions per train descriptor
 // next to 38 vector instructions, in-order returns (counted lgkmcnt waits, reads issued several descriptors ahead).
-// k_match above takes them through scalar loads instead: those return out of order, every trip waited for all of them
-// (lgkmcnt(0)) with nothing in flight, and the kernel sat at 0.42 of the vector issue rate (profiles/r01_sq_counters).
+// (Round 1's kernel took them through scalar loads instead: those return out of order, every trip waited for all of them
+// (lgkmcnt(0)) with nothing in flight, and it sat at 0.42 of the vector issue rate (profiles/r01_sq_counters); it lived on as the path
+// for descriptor arrays that are not 16-byte aligned until round 4, which asks for the alignment instead.)
 #define ML_THREADS 256
 #define ML_Q 2
 #define ML_PER_BLOCK (ML_THREADS * ML_Q)
@@ -394,34 +340,30 @@ int match_launch_pairs(mo_ctx* c, const uint8_t* d_q, const uint8_t* d_t, size_t
         HIPCHK(c, hipGetLastError());
         return MO_OK;
     }
-    const bool al16 = ((((size_t)d_q) | ((size_t)d_t) | q_stride | t_stride) & 15) == 0;
-    if (c->match_mode != 2 && al16) {  // default: LDS-staged train tiles
-        dim3 grid((nq_max + ML_PER_BLOCK - 1) / ML_PER_BLOCK, n_pairs);
-        // a handful of workgroups (the single-pair calls of the host API) would leave most of the 256 CUs idle: slice the train
-        // tiles over gridDim.z and merge the per-slice keys
-        const int ntile = (nt_max + ML_TILE - 1) / ML_TILE, blocks = (int)grid.x * n_pairs;
-        const int n_split = blocks <= ML_SPLIT_BLOCKS ? std::min(std::min(ntile, ML_SPLIT_MAX), 256 / blocks) : 1;
-        if (n_split > 1) {
-            const size_t need = (size_t)n_pairs * n_split * out_stride * sizeof(uint2);
-            if (int rc = mo_reserve(c, c->d_match_part, c->match_part_bytes, need)) return rc;
-            grid.z = n_split;
-            hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf,
-                               d_tf, nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass, c->d_match_part);
-            HIPCHK(c, hipGetLastError());
-            hipLaunchKernelGGL(k_match_merge, dim3((nq_max + 255) / 256, n_pairs), dim3(256), 0, c->stream,
-                               c->d_match_part, n_split, d_counts, d_qf, nq_fixed, out_stride, ratio, d_idx, d_dist,
-                               d_pass);
-            HIPCHK(c, hipGetLastError());
-            return MO_OK;
-        }
-        hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf, d_tf,
-                           nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass, (uint2*)nullptr);
+    // descriptor rows are read as 16-byte pieces: the host entry points stage into their own (aligned) buffers, device callers hand in
+    // hipMalloc'd / torch arrays (256-byte aligned) with rows of cap x 32 bytes
+    if (((((size_t)d_q) | ((size_t)d_t) | q_stride | t_stride) & 15) != 0)
+        return mo_fail(c, MO_ERR_ARG, "descriptor arrays must be 16-byte aligned (base pointers and row strides)");
+    dim3 grid((nq_max + ML_PER_BLOCK - 1) / ML_PER_BLOCK, n_pairs);
+    // a handful of workgroups (the single-pair calls of the host API) would leave most of the 256 CUs idle: slice the train
+    // tiles over gridDim.z and merge the per-slice keys
+    const int ntile = (nt_max + ML_TILE - 1) / ML_TILE, blocks = (int)grid.x * n_pairs;
+    const int n_split = blocks <= ML_SPLIT_BLOCKS ? std::min(std::min(ntile, ML_SPLIT_MAX), 256 / blocks) : 1;
+    if (n_split > 1) {
+        const size_t need = (size_t)n_pairs * n_split * out_stride * sizeof(uint2);
+        if (int rc = mo_reserve(c, c->d_match_part, c->match_part_bytes, need)) return rc;
+        grid.z = n_split;
+        hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf,
+                           d_tf, nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass, c->d_match_part);
+        HIPCHK(c, hipGetLastError());
+        hipLaunchKernelGGL(k_match_merge, dim3((nq_max + 255) / 256, n_pairs), dim3(256), 0, c->stream,
+                           c->d_match_part, n_split, d_counts, d_qf, nq_fixed, out_stride, ratio, d_idx, d_dist,
+                           d_pass);
         HIPCHK(c, hipGetLastError());
         return MO_OK;
     }
-    dim3 grid((nq_max + MQ_PER_BLOCK - 1) / MQ_PER_BLOCK, n_pairs);
-    hipLaunchKernelGGL(k_match, grid, dim3(MQ_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf, d_tf,
-                       nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass);
+    hipLaunchKernelGGL(k_match_lds, grid, dim3(ML_THREADS), 0, c->stream, d_q, d_t, q_stride, t_stride, d_counts, d_qf, d_tf,
+                       nq_fixed, nt_fixed, out_stride, ratio, d_idx, d_dist, d_pass, (uint2*)nullptr);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

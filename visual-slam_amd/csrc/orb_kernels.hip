@@ -18,6 +18,11 @@
 #include <cstring>
 
 #include "common.h"
+// threads of a k_select workgroup (the replay's partition passes, the Harris groups and the strip gather are dealt over its wavefronts)
+#ifndef SEL_THREADS
+#define SEL_THREADS 256
+#endif
+#define WG_THREADS SEL_THREADS
 #include "select_replay.h"
 
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {
@@ -62,6 +67,51 @@ __global__ void k_gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gr
 int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray) {
     size_t npx = (size_t)w * h * batch;
     hipLaunchKernelGGL(k_gray, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, d_bgr, d_gray, npx);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
+
+// Single-frame host calls: the image sits in PINNED host memory (the context's staging buffer) and this kernel is the upload - it
+// reads the mapped host pages over PCIe and writes the dense gray frame in HBM (BGR input is converted on the way, so a colour frame
+// never exists in HBM), and clears the call's flag word.  One launch instead of a copy (+ a fill) (+ k_gray); a runtime copy of a
+// PAGEABLE array is staged by the host thread and took 36 us of a 0.3 ms detect_and_compute call.
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, uint8_t* __restrict__ gray, int npx, int ch, int* flags_clear) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 16;  // 16 pixels per thread
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flags_clear) { flags_clear[0] = 0; flags_clear[1] = 0; flags_clear[2] = 0; flags_clear[3] = 0; }
+    if (i >= npx) return;
+    if (i + 16 <= npx) {
+        if (ch == 1) {
+            *(uint4*)(gray + i) = *(const uint4*)(src + i);
+        } else {
+            const uint4* s4 = (const uint4*)(src + (size_t)3 * i);   // 48 bytes, 16-byte aligned (i is a multiple of 16)
+            const uint4 a = s4[0], b = s4[1], c = s4[2];
+            const uint32_t wsrc[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int byte = 3 * (4 * q + k);
+                    const uint32_t bb = (wsrc[byte >> 2] >> (8 * (byte & 3))) & 255u, gg = (wsrc[(byte + 1) >> 2] >> (8 * ((byte + 1) & 3))) & 255u,
+                                   rr = (wsrc[(byte + 2) >> 2] >> (8 * ((byte + 2) & 3))) & 255u;
+                    v |= ((bb * 3735u + gg * 19235u + rr * 9798u + (1u << 14)) >> 15) << (8 * k);
+                }
+                o[q] = v;
+            }
+            *(uint4*)(gray + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
+    for (int j = i; j < npx; j++) {  // tail of a frame whose pixel count is not a multiple of 16
+        if (ch == 1) gray[j] = src[j];
+        else gray[j] = (uint8_t)(((int)src[3 * (size_t)j] * 3735 + (int)src[3 * (size_t)j + 1] * 19235 + (int)src[3 * (size_t)j + 2] * 9798 + (1 << 14)) >> 15);
+    }
+}
+
+int orb_launch_ingest(mo_ctx* c, const uint8_t* src_mapped, int w, int h, int ch, uint8_t* d_gray, int* flags_clear) {
+    const int npx = w * h;
+    hipLaunchKernelGGL(k_ingest, dim3((unsigned)((npx + 4095) / 4096)), dim3(256), 0, c->stream, src_mapped, d_gray, npx, ch, flags_clear);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
@@ -272,7 +322,7 @@ int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels,
         dim3 grid((d.w - 2 * org + RS_TW - 1) / RS_TW, (d.h - 2 * org + RS_TH - 1) / RS_TH, batch);
         const uint32_t per = grid.x * grid.y, inv_per = per > 1 ? 0xFFFFFFFFu / per + 1u : 0u, inv_gx = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
         const bool al4 = ((((size_t)src) | sfs | (size_t)s.pitch) & 3) == 0 && s.pitch >= 12;
-        if (al4 && t.two_pass_ok && !c->resize_gather)
+        if (al4 && t.two_pass_ok)
             hipLaunchKernelGGL(k_resize2, grid, dim3(256), 0, c->stream, src, sfs, s.pitch, s.w, s.h, c->d_pyr + d.off,
                                (size_t)P.pyr_stride, d.pitch, d.w, d.h, t.xpk, t.ypk, inv_per, inv_gx, org);
         else
@@ -859,7 +909,6 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
     return (((size_t)n * rec_bytes + 7) & ~(size_t)7) + ((((size_t)n / 2 + 1) * 2 + 7) & ~(size_t)7) + ((size_t)n / 64 + 8) * 8;
 }
 
-#define SEL_THREADS 256
 #define HG 8                       // lanes per keypoint in the Harris phase
 #define HG_GROUPS (SEL_THREADS / HG)
 

@@ -416,13 +416,105 @@ __device__ __forceinline__ int wave_pair_partition(P a, int lo, int hi, FL stopL
     return min(minNL, minSR);
 }
 
+// ---------------------------------------------------------------- register-resident tail (libstdc++ order) ---------
+// A range of at most 64 records fits one wavefront with ONE record per lane, and from there on the rest of introselect runs on
+// registers: the median-of-3 reads are v_readlane, the Hoare pairing is two ballots and popcounts (rank of a stopper = stoppers of
+// lower lanes), the swaps are one ds_permute (every swapping record pushes itself to a slot lane: left swapper of rank k to lane k,
+// right swapper of rank k to lane 32 + k; a range of <= 63 partitioned records has at most 31 pairs) and one ds_bpermute (it pulls
+// its partner's record from the opposite slot), the final insertion sort of <= 3 records is scalar code on broadcast values.  About
+// 400 cycles per round against 1.5 - 2 k for a round through LDS arrays, and no serial lane-0 tail (ranges below 32 records were
+// finished by ONE lane walking LDS: 5 - 10 k cycles); typically the last five or six rounds of every replay.
+template <class T> struct LaneOps;
+template <> struct LaneOps<uint32_t> {
+    static __device__ __forceinline__ uint32_t read(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+    static __device__ __forceinline__ uint32_t push(uint32_t v, int dst) { return (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)v); }
+    static __device__ __forceinline__ uint32_t pull(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v); }
+};
+template <> struct LaneOps<uint64_t> {
+    static __device__ __forceinline__ uint64_t read(uint64_t v, int src) {
+        const int s = __builtin_amdgcn_readfirstlane(src);
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), s) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, s);
+    }
+    static __device__ __forceinline__ uint64_t push(uint64_t v, int dst) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)(uint32_t)v);
+    }
+    static __device__ __forceinline__ uint64_t pull(uint64_t v, int src) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)(uint32_t)v);
+    }
+};
+
+#define REPLAY_REG_MAX 64  // ranges this short (and longer than 3) finish in registers
+
+// continuation of ls_introselect on [first, last), 3 < last - first <= 64; all 64 lanes of ONE wavefront, convergent
+template <class T, class P>
+__device__ __forceinline__ void wave_reg_introselect(P a, int first, int nth, int last, int depth, int lane) {
+    typedef Rec<T> R;
+    typedef LaneOps<T> L;
+    const int n = last - first, kth = nth - first;
+    T v = a[first + min(lane, n - 1)];
+    int lo = 0, hi = n;
+    const unsigned long long lt = (1ull << lane) - 1ull, above = lane == 63 ? 0ull : ~0ull << (lane + 1);
+    while (hi - lo > 3) {
+        if (depth == 0) {  // heap-select fallback (never seen on image data): back to the array, one lane
+            if (lane < n) a[first + lane] = v;
+            wave_sync();
+            if (lane == 0) { ls_heap_select<T>(a, first + lo, nth + 1, first + hi); swp(a, first + lo, nth); }
+            wave_sync();
+            return;
+        }
+        --depth;
+        const int mid = lo + (hi - lo) / 2;
+        // __move_median_to_first(result = lo, lo + 1, mid, hi - 1)
+        const T va = L::read(v, lo + 1), vb = L::read(v, mid), vc = L::read(v, hi - 1);
+        int p;
+        if (R::gt(va, vb)) p = R::gt(vb, vc) ? mid : R::gt(va, vc) ? hi - 1 : lo + 1;
+        else p = R::gt(va, vc) ? lo + 1 : R::gt(vb, vc) ? hi - 1 : mid;
+        const T vlo = L::read(v, lo), pv = L::read(v, p);
+        if (lane == lo) v = pv;
+        else if (lane == p) v = vlo;
+        // __unguarded_partition of [lo + 1, hi) around pv, as the rank pairing of wave_pair_partition
+        const bool in = lane > lo && lane < hi;
+        const bool isL = in && !R::gt(v, pv), isR = in && !R::gt(pv, v);
+        const unsigned long long mL = __ballot(isL), mR = __ballot(isR);
+        const int cL = __popcll(mL & lt), cRa = __popcll(mR & above);  // left stoppers strictly before / right stoppers strictly after this lane
+        const bool swL = isL && cRa >= cL + 1, swR = isR && cL >= cRa + 1;
+        const unsigned long long sL = __ballot(swL), sR = __ballot(swR);
+        if (sL) {  // wave-uniform
+            const T got = L::push(v, swL ? cL : swR ? 32 + cRa : 63);   // (lane 63 is no slot: at most 31 pairs)
+            const T mine = L::pull(got, swL ? 32 + cL : swR ? cRa : lane);
+            if (swL || swR) v = mine;
+        }
+        const unsigned long long nl = mL & ~sL;
+        const int minNL = nl ? __ffsll((long long)nl) - 1 : 0x7FFFFFFF, minSR = sR ? __ffsll((long long)sR) - 1 : 0x7FFFFFFF;
+        const int cut = min(minNL, minSR);
+        if (cut <= kth) lo = cut;
+        else hi = cut;
+    }
+    // __insertion_sort of the last <= 3 records
+    const int m = hi - lo;
+    if (m >= 2) {
+        T e0 = L::read(v, lo), e1 = L::read(v, lo + 1), e2 = m == 3 ? L::read(v, lo + 2) : e1;
+        if (R::gt(e1, e0)) { const T t = e0; e0 = e1; e1 = t; }
+        if (m == 3) {
+            if (R::gt(e2, e0)) { const T t = e2; e2 = e1; e1 = e0; e0 = t; }
+            else if (R::gt(e2, e1)) { const T t = e1; e1 = e2; e2 = t; }
+        }
+        if (lane == lo) v = e0;
+        else if (lane == lo + 1) v = e1;
+        else if (m == 3 && lane == lo + 2) v = e2;
+    }
+    if (lane < n) a[first + lane] = v;
+    wave_sync();
+}
+
 template <class T, class P>
 __device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int lane) {
     typedef Rec<T> R;
     if (first == last || nth == last) return;
     int depth = (31 - __clz(last - first)) * 2;
     while (last - first > 3) {
-        if (last - first < REPLAY_SERIAL_BELOW || last - first > 65535 || depth == 0) {
+        if (last - first <= REPLAY_REG_MAX) { wave_reg_introselect<T>(a, first, nth, last, depth, lane); return; }
+        if (last - first > 65535 || depth == 0) {
             if (lane == 0) ls_introselect<T>(a, first, nth, last, depth);  // identical continuation, one lane
             wave_sync();
             return;
@@ -471,18 +563,21 @@ __device__ __forceinline__ int wave_retain_best(P a, int n, int n_points, int or
 }
 
 // ================================================================ workgroup-parallel replay (4 wavefronts) ==========
-// The same pairing partition with the 256-element trips dealt round-robin to the 4 wavefronts of a 256-thread workgroup.
+// The same pairing partition with the 256-element trips dealt round-robin to the WG_WAVES wavefronts of the workgroup.
 // Trip t (elements lo + 256 t ..) needs the number of left / right stoppers in the trips before it: pass 1 leaves the
 // per-trip counts in LDS, one wavefront turns them into exclusive prefix sums (<= 64 trips: one shuffle scan), passes 2
 // and 3 then run independently per trip.  K and the cut are combined over the wavefronts (positions grow with the trip
 // number, so the minimum over the wavefronts' first hits is the global first hit).  All 256 threads call these functions
 // convergently; every branch below depends only on values that are identical in all threads.
+#ifndef WG_THREADS
+#define WG_THREADS 256
+#endif
+#define WG_WAVES (WG_THREADS / 64)
 struct WgScratch {
     int cl[64], cr[64], pl[65], pr[65];
-    int k[4], nl[4], sr[4];
+    int k[WG_WAVES], nl[WG_WAVES], sr[WG_WAVES];
     int cut;
 };
-#define WG_THREADS 256
 #define WG_PARTITION_MIN 384     // shorter ranges: one wavefront does it alone (saves the barriers)
 #define WG_PARTITION_MAX 16384   // 64 trips: what one shuffle scan covers
 
@@ -574,9 +669,9 @@ __device__ __forceinline__ int wg_pair_partition(P a, int lo, int hi, FL stopL, 
     }
     if (lane == 0) { ws->k[wv] = Kw; ws->nl[wv] = minNL; ws->sr[wv] = minSR; }
     __syncthreads();
-    const int K = ws->k[0] + ws->k[1] + ws->k[2] + ws->k[3];
-    const int cut = min(min(min(ws->nl[0], ws->nl[1]), min(ws->nl[2], ws->nl[3])),
-                        min(min(ws->sr[0], ws->sr[1]), min(ws->sr[2], ws->sr[3])));
+    int K = 0, cut = 0x7FFFFFFF;
+#pragma unroll
+    for (int q = 0; q < WG_WAVES; q++) { K += ws->k[q]; cut = min(cut, min(ws->nl[q], ws->sr[q])); }
     // pass 3: the swaps (a left stopper of rank <= K with the right stopper of the same rank)
     for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
         const int baseL = ws->pl[t];
@@ -634,7 +729,12 @@ __device__ __forceinline__ void wg_ls_nth_element(P a, int first, int nth, int l
     if (first == last || nth == last) return;
     int depth = (31 - __clz(last - first)) * 2;
     while (last - first > 3) {
-        if (last - first < REPLAY_SERIAL_BELOW || last - first > 65535 || depth == 0) {
+        if (last - first <= REPLAY_REG_MAX) {  // the rest on the registers of one wavefront
+            if (tid < 64) wave_reg_introselect<T>(a, first, nth, last, depth, tid);
+            __syncthreads();
+            return;
+        }
+        if (last - first > 65535 || depth == 0) {
             if (tid == 0) ls_introselect<T>(a, first, nth, last, depth);  // identical continuation, one lane
             __syncthreads();
             return;

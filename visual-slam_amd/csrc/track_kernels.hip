@@ -7,25 +7,39 @@
 // cv2.findEssentialMat(..., RANSAC, 0.999, 1.0) and cv2.recoverPose (tracker.py:242-249): k_track_select writes that list
 // and the two-view kernels (twoview_kernels.hip) consume it instead of the ratio-test flags.
 //
-// One workgroup per frame pair.  Distances are integers 0..256 and a pair has at most 8192 matches, so the sort key
-// (distance << 16 | query index) is unique and the stable order is its plain order: every survivor counts the smaller keys
-// (LDS broadcast reads; a few hundred survivors per pair) and scatters itself to that rank.  np.median of the sorted list is
-// (d[(n-1)/2] + d[n/2]) / 2, so "distance < 2 * median" is the integer test  distance < d[(n-1)/2] + d[n/2]  and, the
-// list being sorted, the kept matches are a prefix.
+// One workgroup per frame pair.  Distances are integers 0..256, so the stable sort is a counting sort: the ratio-test survivors inside
+// the displacement gate are compacted in query order (key = distance << 23 | query index) while a 257-bin histogram is taken; its
+// exclusive prefix gives every distance its first rank, the median pair d[(n-1)/2], d[n/2] (np.median of the sorted list is their mean,
+// so "distance < 2 * median" is the integer test distance < d[(n-1)/2] + d[n/2]) and - the list being sorted - the number of kept matches,
+// prefix[threshold].  Only the kept matches are then placed: wavefront w walks the compacted list 64 keys at a time and scatters those of
+// ITS distances (d & 3 == w) behind the running count of their bin - ties keep the query order, which is the order Python's stable
+// sorted() leaves them in.  Any number of keypoints per frame: the two key arrays live in LDS up to 6 000 records, in an HBM scratch
+// slot beyond (rounds 2 - 3 ranked every survivor against all others out of LDS: at most 8 192 keypoints, 23 us for one pair).
 #include "common.h"
 
 #define TS_BLOCK 256
+#define TS_KEY_BITS 23
+#define TS_LDS_CAP 6000   // records whose two key arrays fit the default 48 KB of dynamic LDS
+
+__device__ __forceinline__ void ts_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __restrict__ kps, const int32_t* __restrict__ counts,
                                                            const int32_t* __restrict__ qf, const int32_t* __restrict__ tf,
                                                            const int32_t* __restrict__ midx, const int32_t* __restrict__ mdist,
                                                            const uint8_t* __restrict__ mpass, int cap, double max_disp,
+                                                           uint32_t* __restrict__ gkeys /* [pairs][2 * cap] or null: keys in LDS */,
                                                            int32_t* __restrict__ sel /* [pairs][cap][2] */,
                                                            int32_t* __restrict__ sel_dist /* [pairs][cap] or null */,
                                                            int32_t* __restrict__ sel_n /* [pairs] */) {
-    extern __shared__ uint32_t s_key[];  // [cap] keys in query order, then [cap] keys by rank
+    extern __shared__ uint32_t s_dyn[];  // [cap] keys in query order, then [cap] kept keys by rank (when gkeys is null)
+    __shared__ int s_hist[320];          // survivors per distance (257 bins, zero-padded), then their exclusive prefix
+    __shared__ int s_bin[260];           // running placement count per distance
     __shared__ int s_w[TS_BLOCK / 64];
-    __shared__ int s_base;
+    __shared__ int s_base, s_med[2];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int fq = qf ? qf[pair] : pair, ft = tf ? tf[pair] : pair + 1;
     const int nq = min(counts[fq], cap);
@@ -34,10 +48,12 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
     const int32_t* idx = midx + (size_t)pair * cap * 2;
     const int32_t* dst = mdist + (size_t)pair * cap * 2;
     const uint8_t* pass = mpass + (size_t)pair * cap;
-    uint32_t* s_sorted = s_key + cap;
+    uint32_t* keys = gkeys ? gkeys + (size_t)pair * 2 * cap : s_dyn;
+    uint32_t* sorted = keys + cap;
+    for (int b = tid; b < 320; b += TS_BLOCK) s_hist[b] = 0;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    // 1. ratio-test survivors within the displacement limit, compacted in query order
+    // 1. ratio-test survivors within the displacement limit, compacted in query order; histogram of their distances
     for (int b0 = 0; b0 < nq; b0 += TS_BLOCK) {
         const int i = b0 + tid;
         bool ok = i < nq && pass[i];
@@ -46,45 +62,79 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
             const int j = idx[2 * i];
             const double dx = (double)k2[j].x - (double)k1[i].x, dy = (double)k2[j].y - (double)k1[i].y;
             ok = sqrt(dx * dx + dy * dy) <= max_disp;
-            d = dst[2 * i];
+            d = min(max(dst[2 * i], 0), 256);
         }
         const unsigned long long bal = __ballot(ok);
         if (lane == 0) s_w[wv] = __popcll(bal);
         __syncthreads();
         int off = s_base;
         for (int k = 0; k < wv; k++) off += s_w[k];
-        if (ok) s_key[off + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)d << 16) | (uint32_t)i;
+        if (ok) {
+            keys[off + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)d << TS_KEY_BITS) | (uint32_t)i;
+            atomicAdd(&s_hist[d], 1);
+        }
         __syncthreads();
         if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
     const int n = s_base;
-    // 2. rank of every survivor = number of smaller keys (keys are unique) -> sorted order
-    for (int e = tid; e < n; e += TS_BLOCK) {
-        const uint32_t key = s_key[e];
-        int rank = 0;
-        for (int j = 0; j < n; j++) rank += s_key[j] < key ? 1 : 0;  // wave-uniform address: one broadcast read per trip
-        s_sorted[rank] = key;
+    // 2. exclusive prefix of the histogram (one wavefront, five bins per lane)
+    if (wv == 0) {
+        int v[5], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { v[k] = s_hist[lane * 5 + k]; sum += v[k]; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(inc, o, 64); if (lane >= o) inc += up; }
+        int run = inc - sum;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { s_hist[lane * 5 + k] = run; run += v[k]; }
     }
     __syncthreads();
-    // 3. 2 * median = d[(n-1)/2] + d[n/2]; kept = the prefix with distance below it
-    int n_keep = 0;
+    // 3. 2 * median = d[(n-1)/2] + d[n/2]: the bins these two ranks fall into; kept = the distances below that sum = a prefix
+    int n_keep = 0, thr = 0;
     if (n > 0) {
-        const int thr = (int)(s_sorted[(n - 1) >> 1] >> 16) + (int)(s_sorted[n >> 1] >> 16);
-        int cnt = 0;
-        for (int e = tid; e < n; e += TS_BLOCK) cnt += (int)(s_sorted[e] >> 16) < thr ? 1 : 0;
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        if (lane == 0) s_w[wv] = cnt;
+        const int r0 = (n - 1) >> 1, r1 = n >> 1;
+        for (int b = tid; b < 257; b += TS_BLOCK) {
+            const int lo = s_hist[b], hi = s_hist[b + 1];   // (bin 257.. hold n)
+            if (lo <= r0 && r0 < hi) s_med[0] = b;
+            if (lo <= r1 && r1 < hi) s_med[1] = b;
+        }
         __syncthreads();
-        n_keep = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        thr = s_med[0] + s_med[1];
+        n_keep = s_hist[min(thr, 257)];
     }
+    for (int b = tid; b < 257; b += TS_BLOCK) s_bin[b] = s_hist[b];
+    __syncthreads();
+    // 4. stable placement of the kept matches: wavefront w owns the distances with d & 3 == w
+    if (n_keep > 0) {
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int c0 = 0; c0 < n; c0 += 64) {  // (workgroup-uniform trip count)
+            const int e = c0 + lane;
+            const uint32_t key = e < n ? keys[e] : 0xFFFFFFFFu;
+            const int d = (int)(key >> TS_KEY_BITS);
+            const bool mine = e < n && (d & 3) == wv && d < thr;
+            unsigned long long rem = __ballot(mine);
+            while (rem) {  // wave-uniform: one trip per distinct distance among this wavefront's keys of the chunk
+                const int src = __ffsll((long long)rem) - 1;
+                const int dv = __shfl(d, src, 64);
+                const unsigned long long mk = __ballot(mine && d == dv);
+                const int base = s_bin[dv];
+                if (mine && d == dv) sorted[base + __popcll(mk & lt)] = key;
+                if (lane == src) s_bin[dv] = base + __popcll(mk);
+                ts_wave_sync();
+                rem &= ~mk;
+            }
+        }
+    }
+    __syncthreads();
     int32_t* out = sel + (size_t)pair * cap * 2;
     for (int e = tid; e < n_keep; e += TS_BLOCK) {
-        const uint32_t key = s_sorted[e];
-        const int i = key & 0xFFFF;
+        const uint32_t key = sorted[e];
+        const int i = key & ((1u << TS_KEY_BITS) - 1u);
         out[2 * e] = i;
         out[2 * e + 1] = idx[2 * i];
-        if (sel_dist) sel_dist[(size_t)pair * cap + e] = (int)(key >> 16);
+        if (sel_dist) sel_dist[(size_t)pair * cap + e] = (int)(key >> TS_KEY_BITS);
     }
     if (tid == 0) sel_n[pair] = n_keep;
 }
@@ -93,10 +143,18 @@ int track_select_launch(mo_ctx* c, const mo_keypoint* d_kps, const int32_t* d_co
                         const int32_t* d_midx, const int32_t* d_mdist, const uint8_t* d_mpass, int cap, int n_pairs, int w, int h,
                         double disp_frac, int32_t* d_sel, int32_t* d_sel_dist, int32_t* d_sel_n) {
     if (n_pairs <= 0) return MO_OK;
-    if (cap > 8192) return mo_fail(c, MO_ERR_UNSUPPORTED, "tracking filters support at most 8192 keypoints per frame (two key arrays in 64 KB of LDS)");
+    if (cap >= (1 << TS_KEY_BITS)) return mo_fail(c, MO_ERR_UNSUPPORTED, "tracking filters support at most 8 388 607 keypoints per frame");
     const double max_disp = ((double)(w + h) / 2.0) * disp_frac;  // matcher.py:128 ((width + height) / 2.0) * threshold_percent
-    hipLaunchKernelGGL(k_track_select, dim3(n_pairs), dim3(TS_BLOCK), (size_t)cap * 2 * sizeof(uint32_t), c->stream, d_kps, d_counts,
-                       d_qf, d_tf, d_midx, d_mdist, d_mpass, cap, max_disp, d_sel, d_sel_dist, d_sel_n);
+    uint32_t* gkeys = nullptr;
+    size_t lds = (size_t)cap * 2 * sizeof(uint32_t);
+    if (cap > TS_LDS_CAP) {  // frames beyond 6 000 keypoints: the key arrays in an HBM scratch slot per pair
+        int rc = mo_reserve(c, c->d_track_keys, c->track_keys_bytes, (size_t)n_pairs * cap * 2 * sizeof(uint32_t));
+        if (rc) return rc;
+        gkeys = c->d_track_keys;
+        lds = 0;
+    }
+    hipLaunchKernelGGL(k_track_select, dim3(n_pairs), dim3(TS_BLOCK), lds, c->stream, d_kps, d_counts, d_qf, d_tf, d_midx, d_mdist, d_mpass, cap,
+                       max_disp, gkeys, d_sel, d_sel_dist, d_sel_n);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }

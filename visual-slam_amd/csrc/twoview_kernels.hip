@@ -36,6 +36,7 @@ struct TvWork {
     float* xf;         // [pairs][cap][4] the same rounded to float32 (first scoring stage)
     float* px;         // [pairs][cap][4] pixel u1,v1,u2,v2
     int* qidx;         // [pairs][cap] query keypoint index of correspondence i
+    uint8_t* cbits;    // [pairs][cap] k_tv_finish: cheirality bits of correspondence i (4 candidates + "considered")
     int* m;            // [pairs]
     double* surv;      // [pairs][n_hyp][TV_REC] survivors of the first scoring stage, dense from index 0 (any order)
     int* n_alive;      // [pairs] survivors listed so far
@@ -51,7 +52,7 @@ struct TvWork {
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
     size_t p = (size_t)n_pairs, nt = (size_t)((n_hyp + 63) / 64);
-    return p * cap * 4 * sizeof(double) + 2 * p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * sizeof(int) * 2 + 16 +
+    return p * cap * 4 * sizeof(double) + 2 * p * cap * 4 * sizeof(float) + p * cap * sizeof(int) + p * cap + p * sizeof(int) * 2 + 16 +
            p * (size_t)n_hyp * TV_REC * sizeof(double) + p * nt * (sizeof(int2) + sizeof(unsigned long long) + 9 * sizeof(double)) +
            p * sizeof(unsigned long long) + p * 8 * sizeof(double) + 1024;
 }
@@ -72,7 +73,8 @@ static TvWork carve(void* base, int n_pairs, int cap, int n_hyp) {
     w.qidx = (int*)b; b += p * cap * sizeof(int);
     w.m = (int*)b; b += p * sizeof(int);
     w.n_alive = (int*)b; b += p * sizeof(int);
-    w.n_tasks = (int*)b;
+    w.n_tasks = (int*)b; b += 16;
+    w.cbits = b;
     return w;
 }
 
@@ -351,13 +353,15 @@ __device__ inline uint64_t splitmix64(uint64_t& s) {
 }
 
 // 8 distinct sample indices of hypothesis h (shared definition with oracle/geom_oracle.py): c = splitmix64 % m, redrawn
-// while it repeats an earlier index.  m <= 4096, so the 64-bit remainder is taken exactly with three 32-bit
+// while it repeats an earlier index.  For m <= 65536 the 64-bit remainder is taken exactly with three 32-bit
 // multiply-high reductions instead of a software 64-bit division: with M = floor(2^32 / m), q = mulhi(x, M) is
 // floor(x / m) or one less, so x - q m needs one conditional subtraction; and x = hi 2^32 + lo gives
-// x mod m = ((hi mod m) (2^32 mod m) + lo mod m) mod m with every intermediate below 2^25.
+// x mod m = ((hi mod m) (2^32 mod m) + lo mod m) mod m with every intermediate below m^2 + m <= 2^32.  Beyond that
+// (no frame pair of this path gets there) the remainder is the plain 64-bit one.
 __device__ __forceinline__ void sample8(uint64_t seed, int h, int m, int (&idx)[8]) {
     const uint32_t um = (uint32_t)m, q0 = 0xFFFFFFFFu / um, r0 = 0xFFFFFFFFu - q0 * um;
     const uint32_t M = r0 + 1u == um ? q0 + 1u : q0, c32 = r0 + 1u == um ? 0u : r0 + 1u;  // floor(2^32 / m), 2^32 mod m
+    const bool small = m <= 65536;
     auto mod32 = [um, M](uint32_t x) {
         uint32_t r = x - __umulhi(x, M) * um;
         return r >= um ? r - um : r;
@@ -369,7 +373,7 @@ __device__ __forceinline__ void sample8(uint64_t seed, int h, int m, int (&idx)[
         bool dup;
         do {
             const uint64_t z = splitmix64(s);
-            c = (int)mod32(mod32((uint32_t)(z >> 32)) * c32 + mod32((uint32_t)z));
+            c = small ? (int)mod32(mod32((uint32_t)(z >> 32)) * c32 + mod32((uint32_t)z)) : (int)(z % (uint64_t)um);
             dup = false;
 #pragma unroll
             for (int j = 0; j < k; j++) dup |= idx[j] == c;
@@ -547,8 +551,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     const mo_keypoint* k1 = a.d_kps + (size_t)qfr * a.cap;
     const mo_keypoint* k2 = a.d_kps + (size_t)tfr * a.cap;
     if (a.d_sel) {  // tracking mode: the filtered match list in the reference's order (track_kernels.hip)
-        int m = min(a.d_sel_n[pair], a.cap);
-        if (m > TV_MAX_M) { if (tid == 0) atomicOr(&a.flags[0], 8); m = 0; }  // (block-uniform) no model for this pair, status bit 3
+        const int m = min(a.d_sel_n[pair], a.cap);
         const int32_t* sl = a.d_sel + (size_t)pair * a.cap * 2;
         for (int o = tid; o < m; o += TV_BLOCK) {
             const int i = sl[2 * o], j = sl[2 * o + 1];
@@ -591,8 +594,7 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
         if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
         __syncthreads();
     }
-    int m = s_base;
-    if (m > TV_MAX_M) { if (tid == 0) atomicOr(&a.flags[0], 8); m = 0; }  // (block-uniform) no model for this pair, status bit 3
+    const int m = s_base;
     if (tid == 0) w.m[pair] = m;
     if (a.model) tv_hartley(a, w, pair, m);
     tv_f32_copy(a, w, pair, m);
@@ -791,11 +793,12 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_tasks(TwoViewArgs a, TvWork w) 
 // the parts meet in LDS, wavefront 0 combines them and its best key goes to the pair's minimum and, with its matrix, to the slot
 // k_tv_finish looks it up in.  (Four wavefronts of different workgroups with a device-scope fence and a counter instead: 2.4x slower
 // - a release fence writes the L2 of the XCD back.)
-__global__ __launch_bounds__(64 * TV_PARTS) void k_tv_score(TwoViewArgs a, TvWork w) {
+__global__ __launch_bounds__(64 * TV_PARTS) void k_tv_score(TwoViewArgs a, TvWork w, int one_pair) {
     __shared__ double s_part[TV_PARTS][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    if ((int)blockIdx.x >= *w.n_tasks) return;  // block-uniform
-    const int2 tk = w.task[blockIdx.x];
+    // one pair (the single-frame calls): workgroup t IS task t of pair 0, no task table (k_tv_tasks is not launched)
+    if (one_pair ? (int)blockIdx.x * 64 >= w.n_alive[0] : (int)blockIdx.x >= *w.n_tasks) return;  // block-uniform
+    const int2 tk = one_pair ? make_int2(0, (int)blockIdx.x) : w.task[blockIdx.x];
     const int pair = tk.x, t0 = tk.y * 64;
     const int total = w.n_alive[pair];
     const int m = w.m[pair];
@@ -870,6 +873,74 @@ __device__ inline int block_sum_i(int v, int* s_red) {
     return r;
 }
 
+// Smallest eigenvector of the 9x9 normal matrix of a refit on ONE wavefront (rounds 1 - 3: thread 0 alone, LDL^T + at most 16 steps of
+// inverse iteration - 16 k cycles per call, 46 % of this kernel, and with an eigenvalue ratio of 0.5 between the two smallest
+// eigenvalues 16 steps leave an error of 1.5e-5: the iteration ran into its cap on every pair of the benchmark).  Here the matrix is
+// inverted explicitly and the inverse is squared ten times: (M^-1)^(2^10) has the wanted vector as its dominant eigenvector with
+// the eigenvalue ratio raised to the 1024th power (0.99 -> 3e-5, 0.9 -> 1e-47).  Both steps work on the 45 entries of the packed upper
+// triangle, one per lane:
+//   * inverse by the symmetric sweep operator (sweep k: M[k][k] -> -1/d, M[i][k] -> M[i][k]/d, M[i][j] -> M[i][j] - M[i][k] M[k][j]/d;
+//     all nine sweeps give -M^-1 and every intermediate matrix is symmetric), on M / trace + 1e-15 I, pivots clamped at 1e-17;
+//   * B <- (B / trace B)^2, nine products per lane out of LDS.
+// sN: the 45 packed sums (p <= q, row-major) in LDS; sM: 48 doubles of LDS scratch; x[9] in LDS: previous estimate in (its orientation
+// is kept), eigenvector out.  Lanes 0..63 of one wavefront, convergent; returns false (x untouched) when the arithmetic broke down.
+__device__ __forceinline__ int tv_pk(int p, int q) { return p <= q ? p * 9 - (p * (p - 1)) / 2 + (q - p) : q * 9 - (q * (q - 1)) / 2 + (p - q); }
+__device__ __forceinline__ void tv_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ bool wave_smallest_eigvec9(const double* sN, double* sM, double* x, int lane) {
+    int p = 0, q = lane < 45 ? lane : 0;
+    while (q >= 9 - p) { q -= 9 - p; p++; }  // packed index -> (p, p + q)
+    q += p;
+    const bool on = lane < 45;
+    double tr = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) tr += sN[tv_pk(k, k)];
+    if (!(tr > 0.0)) return false;  // (wave-uniform: every lane read the same nine values)
+    const double itr = 1.0 / tr;
+    if (on) sM[lane] = sN[lane] * itr + (p == q ? 1e-15 : 0.0);
+    tv_wave_sync();
+    for (int k = 0; k < 9; k++) {  // sweep k
+        const double d = fmax(sM[tv_pk(k, k)], 1e-17), id = 1.0 / d;
+        const double a = sM[tv_pk(p, k)], b = sM[tv_pk(k, q)], c = sM[lane < 45 ? lane : 0];
+        const double nv = p == k && q == k ? -id : p == k ? b * id : q == k ? a * id : c - a * b * id;
+        tv_wave_sync();
+        if (on) sM[lane] = nv;
+        tv_wave_sync();
+    }
+    // sM = -(M^-1); its square is the square of M^-1
+    for (int it = 0; it < 10; it++) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) t += sM[tv_pk(k, k)];
+        const double sc = 1.0 / t;  // (trace of a definite matrix: never 0; negative in the first round, squared away)
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc += sM[tv_pk(p, k)] * sM[tv_pk(k, q)];
+        acc *= sc * sc;
+        tv_wave_sync();
+        if (on) sM[lane] = acc;
+        tv_wave_sync();
+    }
+    // the column with the largest diagonal entry, normalised, oriented like the previous estimate
+    int jb = 0;
+    double best = sM[tv_pk(0, 0)];
+#pragma unroll
+    for (int k = 1; k < 9; k++) { const double v = sM[tv_pk(k, k)]; if (v > best) { best = v; jb = k; } }
+    double nn = 0.0, dot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const double v = sM[tv_pk(k, jb)]; nn += v * v; dot += v * x[k]; }
+    if (!(nn > 0.0) || !(nn < 1e300)) return false;  // NaN / overflow somewhere (wave-uniform)
+    const double sgn = (dot < 0 ? -1.0 : 1.0) / sqrt(nn);
+    const double mine = lane < 9 ? sM[tv_pk(lane, jb)] * sgn : 0.0;
+    tv_wave_sync();
+    if (lane < 9) x[lane] = mine;
+    tv_wave_sync();
+    return true;
+}
+
 __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w) {
     __shared__ double s_red[TVF_BLOCK / 64];
     __shared__ int s_redi[TVF_BLOCK / 64];
@@ -919,7 +990,7 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     // adaptively tightened consensus set.  The selection threshold follows a 3-sigma rule on the mean Sampson
     // residual of the previous selection, clamped to [thr/64, thr], so chance inliers of the loose RANSAC threshold
     // do not bias the algebraic fit; a refit is only accepted while >= half of the original consensus is selected.
-    __shared__ double s_N[45];
+    __shared__ double s_N[45], s_M[48], s_x[9];
     __shared__ double s_R[TVF_BLOCK * 9];          // constraint rows of one pass
     __shared__ double s_tile[TVF_BLOCK / 64][256];  // per-wavefront partial Gram tiles
     __shared__ int s_stop;
@@ -1004,16 +1075,23 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
             s_N[tid] = v;
         }
         __syncthreads();
-        if (tid == 0) {  // smallest eigenvector of the normal matrix, seeded with the current estimate
-            double E[9], Nn[45], en = 0;
-            for (int i = 0; i < 45; i++) Nn[i] = s_N[i];
-            for (int i = 0; i < 9; i++) { E[i] = s_E[i]; en += E[i] * E[i]; }
-            en = 1.0 / sqrt(en);
-            for (int i = 0; i < 9; i++) E[i] *= en;
-            smallest_eigvec<9>(Nn, E, 16);
-            bool ok = a.model ? project_rank2(E) : project_essential(E);
-            if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
-            s_stop = ok ? 0 : 1;
+        // smallest eigenvector of the normal matrix on wavefront 0 (the current estimate only fixes the sign), then the projection on
+        // the essential / rank-2 manifold by one lane
+        if (tid < 64) {
+            if (tid < 9) {
+                double en = 0;
+                for (int i = 0; i < 9; i++) en += s_E[i] * s_E[i];
+                s_x[tid] = s_E[tid] / sqrt(en);
+            }
+            tv_wave_sync();
+            const bool conv = wave_smallest_eigvec9(s_N, s_M, s_x, tid);
+            if (tid == 0) {
+                double E[9];
+                for (int i = 0; i < 9; i++) E[i] = s_x[i];
+                const bool ok = conv && (a.model ? project_rank2(E) : project_essential(E));
+                if (ok) for (int i = 0; i < 9; i++) s_E[i] = E[i];  // else keep the previous estimate
+                s_stop = ok ? 0 : 1;
+            }
         }
         __syncthreads();
         if (s_stop) break;
@@ -1101,11 +1179,10 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     const double dist = 50.0;
     int good[4] = {0, 0, 0, 0};
-    unsigned char cmask[(2048 + TVF_BLOCK - 1) / TVF_BLOCK * 2];  // per-thread bits for up to 4096 points
+    uint8_t* cbits = w.cbits + (size_t)pair * a.cap;  // per correspondence: bit cnd = in front of both cameras under candidate cnd
     double E[9];
     for (int j = 0; j < 9; j++) E[j] = s_E[j];
-    int slot = 0;
-    for (int i = tid; i < m; i += TVF_BLOCK, slot++) {
+    for (int i = tid; i < m; i += TVF_BLOCK) {
         double x1 = xn[4 * i], y1 = xn[4 * i + 1], x2 = xn[4 * i + 2], y2 = xn[4 * i + 3];
         unsigned bits = 0;
         const bool consider = given ? (!a.d_mask_in || a.d_mask_in[(size_t)pair * a.cap + qidx[i]] != 0) : sampson(E, x1, y1, x2, y2) <= thr2;
@@ -1125,7 +1202,7 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
             bits |= 16u;
             if (ran_out) ran_out[qidx[i]] = 1;
         }
-        if (slot < (int)sizeof(cmask)) cmask[slot] = (unsigned char)bits;
+        cbits[i] = (uint8_t)bits;  // (read back by the same thread below)
     }
     int g[4];
     for (int cnd = 0; cnd < 4; cnd++) g[cnd] = block_sum_i(good[cnd], s_redi);
@@ -1156,9 +1233,8 @@ __global__ __launch_bounds__(TVF_BLOCK) void k_tv_finish(TwoViewArgs a, TvWork w
     const int win = s_win;
     double Pa[12], Pb[12];
     for (int j = 0; j < 12; j++) { Pa[j] = s_Ppix[0][j]; Pb[j] = s_Ppix[1][j]; }
-    slot = 0;
-    for (int i = tid; i < m; i += TVF_BLOCK, slot++) {
-        unsigned bits = slot < (int)sizeof(cmask) ? cmask[slot] : 0;
+    for (int i = tid; i < m; i += TVF_BLOCK) {
+        const unsigned bits = cbits[i];
         if (!((bits >> win) & 1u)) continue;
         double X[4];
         dlt_point(Pa, Pb, (double)px[4 * i], (double)px[4 * i + 1], (double)px[4 * i + 2], (double)px[4 * i + 3], X);
@@ -1190,9 +1266,7 @@ int triangulate_launch(mo_ctx* c, const double* P1, const double* P2, const floa
 
 int twoview_launch(mo_ctx* c, const TwoViewArgs& a_in) {
     if (a_in.n_pairs <= 0) return MO_OK;
-    // (rows may be longer than TV_MAX_M - a batch extracted with 6000 features per frame: what counts is the number of
-    //  correspondences of a pair, checked on the device; explicit point lists are checked by their entry points)
-    if (a_in.d_p1 && a_in.m_fixed > TV_MAX_M) return mo_fail(c, MO_ERR_UNSUPPORTED, "two-view stage supports at most 4096 correspondences per pair");
+    // (a pair takes any number of correspondences: the sampler is exact for every m, the per-correspondence state lives in the workspace)
     TwoViewArgs a = a_in;
     a.flags = c->flags_cur ? c->flags_cur : c->d_flags;
     if (!a.d_E_in && (a.n_hyp < 1 || a.n_hyp > (1 << 20))) return mo_fail(c, MO_ERR_ARG, "n_hyp out of range");
@@ -1207,11 +1281,12 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a_in) {
         return MO_OK;
     }
     const int staged = a.n_hyp >= 512;  // below that the bound of one or two blocks prunes too little to pay for the second stage
-    static const int first_num = [] { const char* e = getenv("VSLAM_AMD_TV_FIRST"); int v = e ? atoi(e) : TV_FIRST_NUM; return v >= 1 && v <= 8 ? v : TV_FIRST_NUM; }();
+    const int first_num = TV_FIRST_NUM;
     hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged, first_num);
     if (staged) {
-        hipLaunchKernelGGL(k_tv_tasks, dim3(1), dim3(TV_BLOCK), 0, c->stream, a, w);
-        hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64 * TV_PARTS), 0, c->stream, a, w);
+        const int one_pair = a.n_pairs == 1;
+        if (!one_pair) hipLaunchKernelGGL(k_tv_tasks, dim3(1), dim3(TV_BLOCK), 0, c->stream, a, w);
+        hipLaunchKernelGGL(k_tv_score, dim3((unsigned)((a.n_hyp + 63) / 64) * a.n_pairs), dim3(64 * TV_PARTS), 0, c->stream, a, w, one_pair);
     }
     hipLaunchKernelGGL(k_tv_finish, dim3(a.n_pairs), dim3(TVF_BLOCK), 0, c->stream, a, w);
     HIPCHK(c, hipGetLastError());

@@ -56,27 +56,31 @@ def convert_to_3d_points(points_4d):
 
 
 def track_from_last_frame(last_keypoints, last_descriptors, keypoints, descriptors, camera_matrix, image_shape,
-                          ratio_threshold=0.75, threshold_percent=0.02, ransac_threshold=1.0):
+                          ratio_threshold=0.75, threshold_percent=0.02, ransac_threshold=1.0, pair_index=0):
     """The body of the reference's Tracker._track_from_last_frame (tracker.py:198-266) as ONE device call: matcher.match ->
     filter_matches_by_geometric_distance (threshold_percent of (w + h) / 2) -> filter_matches_by_distance (2 x median) ->
     cv2.findEssentialMat(RANSAC, 0.999, 1.0) -> cv2.recoverPose.  Tracker calls cv2 directly for the last two, so the caller
     needs this one-line replacement.  -> (success, T 4x4 float64, inlier matches as DMatch list); like the
-    reference it fails with fewer than 8 filtered matches or without a valid essential matrix."""
+    reference it fails with fewer than 8 filtered matches or without a valid essential matrix.
+    When the arguments are the very arrays detect_and_compute returned for the last two frames, both are still resident on the device
+    and nothing is uploaded.  pair_index (an extension): position of this pair in the sequence - a loop that counts its pairs draws
+    the sampling streams of the batched mode (vslam_amd.stream) and gets its poses bit for bit."""
     from .types import dmatches_from_arrays, keypoints_to_array
     if last_keypoints is None or last_descriptors is None or descriptors is None:
         return False, None, []
     h, w = image_shape[:2]
     r = vslam_amd.default_context().track_pair(keypoints_to_array(last_keypoints), last_descriptors, keypoints_to_array(keypoints),
                                                descriptors, w, h, camera_matrix, ratio=ratio_threshold,
-                                               disp_frac=threshold_percent, thr_px=ransac_threshold, n_hyp=N_HYPOTHESES, seed=SEED)
+                                               disp_frac=threshold_percent, thr_px=ransac_threshold, n_hyp=N_HYPOTHESES, seed=SEED,
+                                               pair_index=pair_index)
     if len(r["sel"]) < 8 or not np.isfinite(r["R"]).all():
         return False, None, []
     T = np.eye(4)
     T[:3, :3] = r["R"]
     T[:3, 3] = r["t"].reshape(3)
-    ok = np.asarray(r["inlier"]).astype(bool).reshape(-1)
-    sel = np.asarray(r["sel"]).reshape(-1, 2)[ok]
-    inliers = dmatches_from_arrays(sel[:, 0], sel[:, 1], np.asarray(r["sel_dist"]).reshape(-1)[ok])
+    ok = r["inlier"]
+    sel = r["sel"][ok]
+    inliers = dmatches_from_arrays(sel[:, 0], sel[:, 1], r["sel_dist"][ok])
     return True, T, inliers
 
 

@@ -6,6 +6,7 @@ built library, or without a HIP device, every call fails loudly (NativeUnavailab
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -52,6 +53,22 @@ class BatchIO(C.Structure):
                 ("d_kf_P2", C.c_void_p), ("d_kf_F", C.c_void_p)]
 
 
+class FrameRef(C.Structure):
+    _fields_ = [("token", C.c_uint64), ("kps", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32)]
+
+
+class PairParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("ratio", C.c_double), ("disp_frac", C.c_double),
+                ("K", C.c_double * 9), ("thr_px", C.c_double), ("n_hyp", C.c_int32), ("seed", C.c_uint64), ("pair_index", C.c_uint64)]
+
+
+class PairOut(C.Structure):
+    _fields_ = [("match_idx", C.c_void_p), ("match_dist", C.c_void_p), ("match_pass", C.c_void_p), ("sel_idx", C.c_void_p),
+                ("sel_dist", C.c_void_p), ("inlier", C.c_void_p), ("ransac", C.c_void_p), ("X", C.c_void_p),
+                ("R", C.c_double * 9), ("t", C.c_double * 3), ("E", C.c_double * 9), ("n_sel", C.c_int32), ("n_good", C.c_int32),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("token1", C.c_uint64), ("token2", C.c_uint64)]
+
+
 MODE_INIT, MODE_TRACK, MODE_KEYFRAME = 0, 1, 2
 DETECT_ORB, DETECT_GRID = 0, 1
 TIMING_SLOTS = 64  # MO_TIMING_SLOTS of the library: event sets kept for Context.stage_times(back)
@@ -72,6 +89,7 @@ SIGNATURES = {
     "mo_orb_grid_good_features": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mo_orb_grid_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mo_dbg_min_eigen": (_i, [_vp, _vp, _i, _i, _vp]),
+    "mo_dbg_set_poison": (_i, [_vp, _i]),
     "mo_undistort": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_dev_undistort": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mo_match_knn2_ratio": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -89,6 +107,10 @@ SIGNATURES = {
     "mo_comm_init": (_i, [_vp, _vp, _i, _i]),
     "mo_comm_destroy": (_i, [_vp]),
     "mo_gather_map_points": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mo_host_times": (_i, [_vp, _vp]),
+    "mo_set_host_timing": (_i, [_vp, _i]),
+    "mo_last_token": (_i, [_vp, _vp]),
+    "mo_pair_frontend": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mo_stage_times": (_i, [_vp, _vp, _vp, _i]),
     "mo_stage_times_back": (_i, [_vp, _i, _vp, _vp, _i]),
     "mo_dbg_pyramid_level": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -152,6 +174,37 @@ def device_count():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# Resident single-frame results: descriptor array (by identity) -> (token, context, the keypoint record array it came with).  A frame's
+# keypoints and descriptors stay on the device after detect_and_compute (the library keeps the last four); when the SAME arrays come
+# back for a pair step (matcher.match, track_from_last_frame, MapInitializer.initialize) nothing is uploaded.  The arrays are handed
+# out read-only so that the device copy cannot go stale behind an in-place write (a copy of them is an ordinary, writable array).
+_resident = {}
+
+
+def _bind_resident(ctx, token, kps_arr, desc):
+    if not token or desc is None:
+        return
+    desc.flags.writeable = False
+    kps_arr.flags.writeable = False
+    key = id(desc)
+    _resident[key] = (token, weakref.ref(ctx), weakref.ref(desc, lambda _, key=key: _resident.pop(key, None)), weakref.ref(kps_arr))
+
+
+def resident_token(ctx, desc, kps_arr=None):
+    """token under which (kps_arr, desc) are resident in ctx, 0 if they are not these very arrays (or were never resident)"""
+    e = _resident.get(id(desc))
+    if e is None or e[1]() is not ctx or e[2]() is not desc:
+        return 0
+    if kps_arr is not None and e[3]() is not kps_arr:
+        return 0
+    return e[0]
+
+
+def _resident_kps(desc):
+    e = _resident.get(id(desc))
+    return e[3]() if e is not None and e[2]() is desc else None
 
 
 def orb_params(nfeatures=2000, scale_factor=1.2, nlevels=8, edge_threshold=31, fast_threshold=7,
@@ -236,6 +289,16 @@ class Context:
             self._check(n)
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
+    def set_host_timing(self, on):
+        """stage events inside the single-call host entry points (off by default: they idle the GPU between kernels)"""
+        self._check(self.lib.mo_set_host_timing(self.h, int(bool(on))))
+
+    def host_times(self):
+        """host-side clock of the last single-call host entry point: dict(enqueue_us, wait_us, unpack_us, total_us)"""
+        us = (C.c_double * 4)()
+        self._check(self.lib.mo_host_times(self.h, us))
+        return dict(enqueue_us=us[0], wait_us=us[1], unpack_us=us[2], total_us=us[3])
+
     # ---- host API ---------------------------------------------------------------------------------------
     def orb_detect_compute(self, images, prm, want_desc=True, cap=None):
         """images: (H,W) / (H,W,3) / (B,H,W) / (B,H,W,3) uint8 -> list of (kps structured array, desc or None)"""
@@ -258,11 +321,18 @@ class Context:
                 continue
             self._check(rc)
             break
+        self.last_token = 0
+        if b == 1 and want_desc:  # the result stays resident on the device under this token (pair_frontend takes it back)
+            tok = C.c_uint64(0)
+            self.lib.mo_last_token(self.h, C.byref(tok))
+            self.last_token = int(tok.value)
         out = []
         for f in range(b):
             n = int(counts[f])
             # views of this call's own buffers (fresh per call, nobody else holds them): no second copy of 120 KB per frame
             out.append((kps[f, :n], desc[f, :n] if want_desc and n else None))
+        if self.last_token:
+            _bind_resident(self, self.last_token, out[0][0], out[0][1])
         return out
 
     def orb_compute(self, image, prm, kps_in):
@@ -323,6 +393,11 @@ class Context:
 
     def match_knn2_ratio(self, q, t, ratio=None):
         """q (nq,32) or (B,nq,32), t likewise -> idx (..,nq,2) i32, dist (..,nq,2) i32, pass (..,nq) bool"""
+        if getattr(q, "ndim", 0) == 2 and _resident:
+            tq, tt = resident_token(self, q), resident_token(self, t)
+            if tq and tt:  # both frames are still on the device: the matcher alone through the pair call, nothing uploaded
+                r = self.pair_frontend(_resident_kps(q), q, _resident_kps(t), t, MODE_INIT, np.eye(3), ratio=ratio, n_hyp=0, token1=tq, token2=tt)
+                return r["idx"], r["dist"], r["keep"]
         q = np.ascontiguousarray(q, np.uint8)
         t = np.ascontiguousarray(t, np.uint8)
         single = q.ndim == 2
@@ -378,25 +453,63 @@ class Context:
             return None, np.zeros(m, bool)
         return F.reshape(3, 3), mask[:m].astype(bool)
 
+    def pair_frontend(self, kps1, desc1, kps2, desc2, mode, K, width=0, height=0, ratio=0.75, disp_frac=0.02, thr_px=None, n_hyp=4096,
+                      seed=4096, pair_index=0, token1=0, token2=0, want_matches=None):
+        """matcher -> (tracking filters) -> two-view stage on one frame pair in ONE device call (mo_pair_frontend).  kps*: structured
+        KP_DTYPE arrays, desc*: (N, 32) uint8; token*: tokens of resident single-frame results (0: upload the arrays).
+        MODE_INIT  -> dict(idx (n1, 2), dist (n1, 2), keep (n1,) bool, R, t, E, ransac_mask (n1,), pose_mask (n1,), X (n1, 3), n_good)
+        MODE_TRACK -> dict(sel (n, 2) [queryIdx, trainIdx] in the reference's order, sel_dist, inlier (n,) bool, R, t, E, n_inliers)
+        both carry token1 / token2: the names under which the two frames are resident now"""
+        token1 = token1 or resident_token(self, desc1, kps1)   # (identity of the arrays detect_and_compute handed out)
+        token2 = token2 or resident_token(self, desc2, kps2)
+        k1 = np.ascontiguousarray(kps1, KP_DTYPE).reshape(-1); k2 = np.ascontiguousarray(kps2, KP_DTYPE).reshape(-1)
+        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
+        n1, n2 = len(k1), len(k2)
+        if len(d1) != n1 or len(d2) != n2:
+            raise ValueError("keypoints and descriptor rows differ in number (%d / %d, %d / %d)" % (n1, len(d1), n2, len(d2)))
+        f1 = FrameRef(int(token1), _ptr(k1), _ptr(d1), n1); f2 = FrameRef(int(token2), _ptr(k2), _ptr(d2), n2)
+        pp = PairParams()
+        pp.mode = int(mode); pp.w = int(width); pp.h = int(height); pp.ratio = float(ratio if ratio is not None else -1.0)
+        pp.disp_frac = float(disp_frac); pp.thr_px = float(thr_px if thr_px is not None else (1.0 if mode == MODE_TRACK else 3.0))
+        pp.n_hyp = int(n_hyp); pp.seed = int(seed); pp.pair_index = int(pair_index)
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        for i in range(9):
+            pp.K[i] = Kc[i]
+        o = PairOut()
+        m1 = max(n1, 1)
+        init = mode == MODE_INIT
+        if want_matches is None:
+            want_matches = init
+        if want_matches:
+            idx = np.empty((m1, 2), np.int32); dist = np.empty((m1, 2), np.int32); keep = np.empty(m1, np.uint8)
+            o.match_idx, o.match_dist, o.match_pass = _ptr(idx), _ptr(dist), _ptr(keep)
+        inl = np.zeros(m1, np.uint8)
+        o.inlier = _ptr(inl)
+        if init:
+            ran = np.zeros(m1, np.uint8); X = np.empty((m1, 3), np.float32)
+            o.ransac, o.X = _ptr(ran), _ptr(X)
+        else:
+            sel = np.empty((m1, 2), np.int32); sd = np.empty(m1, np.int32)
+            o.sel_idx, o.sel_dist = _ptr(sel), _ptr(sd)
+        self._check(self.lib.mo_pair_frontend(self.h, C.byref(f1), C.byref(f2), C.byref(pp), C.byref(o)))
+        r = dict(R=np.array(o.R[:]).reshape(3, 3), t=np.array(o.t[:]).reshape(3, 1), E=np.array(o.E[:]).reshape(3, 3),
+                 token1=int(o.token1), token2=int(o.token2))
+        if want_matches:
+            r.update(idx=idx[:n1], dist=dist[:n1], keep=keep[:n1].view(bool))
+        if init:
+            r.update(ransac_mask=ran[:n1].view(bool), pose_mask=inl[:n1].view(bool), X=X[:n1], n_good=int(o.n_good))
+        else:
+            n = int(o.n_sel)
+            r.update(sel=sel[:n], sel_dist=sd[:n], inlier=inl[:n].view(bool), n_inliers=int(o.n_good))
+        return r
+
     def track_pair(self, kps1, desc1, kps2, desc2, width, height, K, ratio=0.75, disp_frac=0.02, thr_px=1.0, n_hyp=4096,
-                   seed=4096):
+                   seed=4096, pair_index=0, token1=0, token2=0):
         """One tracking step (reference tracker.py:214-254) on the device: match -> displacement filter -> 2 x median distance
         filter -> essential matrix at thr_px -> pose.  kps*: structured KP_DTYPE arrays, desc*: (N, 32) uint8.
         -> dict(sel (n, 2) int32 [queryIdx, trainIdx] in the reference's order, sel_dist, inlier (n,) bool, R, t, E, n_inliers)"""
-        k1 = np.ascontiguousarray(kps1, KP_DTYPE); k2 = np.ascontiguousarray(kps2, KP_DTYPE)
-        d1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32); d2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
-        n1, n2 = len(k1), len(k2)
-        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
-        R = np.zeros(9); t = np.zeros(3); E = np.zeros(9)
-        sel = np.zeros((max(n1, 1), 2), np.int32); sd = np.zeros(max(n1, 1), np.int32); inl = np.zeros(max(n1, 1), np.uint8)
-        ns, ni = C.c_int(0), C.c_int(0)
-        self._check(self.lib.mo_track_pair(self.h, _ptr(k1), n1, _ptr(d1), _ptr(k2), n2, _ptr(d2), int(width), int(height),
-                                           float(ratio if ratio is not None else -1.0), float(disp_frac), _ptr(Kc), float(thr_px),
-                                           int(n_hyp), C.c_uint64(int(seed)), _ptr(R), _ptr(t), _ptr(E), _ptr(sel), _ptr(sd),
-                                           C.byref(ns), _ptr(inl), C.byref(ni)))
-        n = ns.value
-        return dict(sel=sel[:n].copy(), sel_dist=sd[:n].copy(), inlier=inl[:n].astype(bool), R=R.reshape(3, 3), t=t.reshape(3, 1),
-                    E=E.reshape(3, 3), n_inliers=ni.value)
+        return self.pair_frontend(kps1, desc1, kps2, desc2, MODE_TRACK, K, width, height, ratio, disp_frac, thr_px, n_hyp, seed, pair_index,
+                                  token1, token2, want_matches=False)
 
     def triangulate_points(self, P1, P2, p1, p2):
         P1 = np.ascontiguousarray(P1, np.float64).reshape(12)
