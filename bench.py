@@ -644,18 +644,94 @@ def main():
                 return round(sorted(ts)[len(ts) // 2], 3)
             (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
             ctx1 = V.default_context()
+
+            def breakdown(fn, n=20):
+                """batch-1 latency split of one host call: wall and the C call's own clocks (entry -> enqueued -> stream waited ->
+                unpacked) with the stage events off (the default), then the device spans of the same call with them on"""
+                ctx1.set_host_timing(False)
+                fn(); ts, hs = [], []
+                for _ in range(n):
+                    t = time.perf_counter(); fn(); ts.append((time.perf_counter() - t) * 1e3); hs.append(ctx1.host_times())
+                wall = float(np.median(ts))
+                hm = {k: float(np.median([h[k] for h in hs])) / 1e3 for k in hs[0]}
+                ctx1.set_host_timing(True)
+                fn(); ev = []
+                for _ in range(max(5, n // 2)):
+                    fn(); ev.append(dict(ctx1.stage_times()))
+                ctx1.set_host_timing(False)
+                dev = {k: round(float(np.median([e[k] for e in ev])), 4) for k in ev[0]}
+                kern = sum(v for k, v in dev.items() if k not in ("h2d", "d2h"))
+                return {"wall_ms": round(wall, 4), "python_binding_ms": round(wall - hm["total_us"], 4), "c_enqueue_ms": round(hm["enqueue_us"], 4),
+                        "c_wait_ms": round(hm["wait_us"], 4), "c_unpack_ms": round(hm["unpack_us"], 4),
+                        "device_h2d_ms": dev.get("h2d"), "device_d2h_ms": dev.get("d2h"), "device_kernels_ms": round(kern, 4),
+                        "device_stage_ms": dev,
+                        "launch_sync_overhead_ms": round(hm["enqueue_us"] + hm["wait_us"] - sum(dev.values()), 4)}
+            # a Tracker in TRACKING state (tracker.py:87,198-266): every frame extracted once and tracked against the previous one, whose
+            # keypoints / descriptors are still resident on the device (the very arrays detect_and_compute handed out come back)
+            trk = {"last": ex.detect_and_compute(f0), "i": 0}
+
+            def tracker_frame():
+                trk["i"] ^= 1
+                cur = ex.detect_and_compute(f1 if trk["i"] else f0)
+                r = geom.track_from_last_frame(trk["last"][0], trk["last"][1], cur[0], cur[1], K, f1.shape)
+                trk["last"] = cur
+                return r
+            from orbslam2.initializer import MapInitializer
+            import contextlib, io as _io
+
+            def initialize_pair():
+                ini = MapInitializer(K)
+                ini.set_first_frame(k0, d0, f0)
+                with contextlib.redirect_stdout(_io.StringIO()):
+                    return ini.initialize(k1, d1, mt, f1)
             out["single_frame_ms"] = {
                 "detect_and_compute": med_ms(lambda: ex.detect_and_compute(f0), 20),
                 "detect_and_compute_all_objects": med_ms(lambda: tuple(ex.detect_and_compute(f0)[0]), 20),
                 "detect_and_compute_native_arrays": med_ms(lambda: ctx1.orb_detect_compute(f0, ex.orb.prm), 20),
+                "extract_features_distributed": med_ms(lambda: ex.extract_features(f0, distributed=True), 10),
+                "tracker_frame": med_ms(tracker_frame, 20)}
+            (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)   # (the last two extractions: both resident)
+            out["single_frame_ms"].update({
                 "match_2000x2000": med_ms(lambda: mt.match(d0, d1), 20),
                 "match_native_arrays": med_ms(lambda: ctx1.match_knn2_ratio(d0, d1, 0.75), 20),
-                "extract_features_distributed": med_ms(lambda: ex.extract_features(f0, distributed=True), 10),
-                "tracker_frame": med_ms(lambda: geom.track_from_last_frame(k0, d0, *ex.detect_and_compute(f1), K, f1.shape), 20),
-                "note": "median wall ms per call, host numpy in / Python objects out (H2D + kernels + D2H + sync); detect_and_compute "
-                        "returns a lazy KeyPoint sequence (objects are built when a caller indexes or iterates it: the *_all_objects "
-                        "row forces all 2000); the *_native_arrays rows stop at numpy arrays; tracker_frame = what a Tracker pays per "
-                        "frame in TRACKING state through the classes: detect_and_compute + track_from_last_frame (tracker.py:87,198-266)"}
+                "track_from_last_frame": med_ms(lambda: geom.track_from_last_frame(k0, d0, k1, d1, K, f1.shape), 20),
+                "initialize": med_ms(initialize_pair, 10)})
+            out["single_frame_ms"]["breakdown"] = {
+                "detect_and_compute": breakdown(lambda: ctx1.orb_detect_compute(f0, ex.orb.prm))}
+            (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
+            out["single_frame_ms"]["breakdown"]["track_pair_resident"] = breakdown(lambda: ctx1.track_pair(k0.array, d0, k1.array, d1, W, H, K))
+            out["single_frame_ms"]["breakdown"]["match_resident"] = breakdown(lambda: ctx1.match_knn2_ratio(d0, d1, 0.75))
+            out["single_frame_ms"]["note"] = (
+                "BASELINE config 2, median wall ms per call through the drop-in classes, host numpy in / Python objects out: the image goes "
+                "through pinned staging and an upload kernel, results stay resident on the device (tokens) and come back through one pack "
+                "kernel, one synchronisation per call; tracker_frame = what a Tracker pays per frame in TRACKING state: detect_and_compute + "
+                "track_from_last_frame on resident frames (tracker.py:87,198-266); initialize = MapInitializer.initialize as ONE device "
+                "call; detect_and_compute returns a lazy KeyPoint sequence (*_all_objects forces all 2000 objects); breakdown: wall and the "
+                "C call's clocks with the stage events off, device spans (hipEvents) of the same call with them on")
+            # (d) the same frames as a SEQUENCE through vslam_amd.stream.FrameStream (mo_stream): host frames in, per-frame results out,
+            #     chunks of 64 through the batched mode with the upload double-buffered - what a driver that can look ahead gets
+            from vslam_amd.stream import FrameStream
+            host_frames = pl.frames.cpu().numpy()
+            legs = {}
+            for name, kw in (("track_orb", dict()), ("track_orb_views", dict(copy=False)), ("track_grid_views", dict(copy=False, detector=V.DETECT_GRID))):
+                fs = FrameStream(K, width=W, height=H, chunk=64, n_features=NFEAT, cap=CAP, n_hyp=N_HYP, **kw)
+                try:
+                    n_seen = sum(1 for _ in fs.run(iter(host_frames[:130])))   # (warm-up: plan, buffers, clocks)
+                    reps = max(2, args.steps // 5)
+                    t1 = time.perf_counter()
+                    n_seen = 0
+                    for _ in range(reps):
+                        for r in fs.run(iter(host_frames)):
+                            n_seen += 1
+                    el = time.perf_counter() - t1
+                finally:
+                    fs.close()
+                legs[name] = {"value": round(n_seen / el, 1), "unit": "frames/s", "frames": n_seen, "ms_per_64_frame_chunk": round(el / n_seen * 64e3, 3)}
+            legs["note"] = ("FrameStream over the bench's own frames as pageable host arrays, chunk 64: staging into pinned memory (host threads), "
+                            "H2D, one mo_dev_frontend_batch per chunk in tracking mode (ratio test, 2 filters, 8-pt RANSAC %d hyp at 1 px), results "
+                            "D2H, one Python FrameResult per frame; *_views: result arrays are views of the pinned buffer instead of copies; "
+                            "track_grid: the detector Tracker uses by default (distribute_keypoints)" % N_HYP)
+            out["streaming"] = legs
         out["dev_status"] = dict(status, note="mo_dev_status after every leg's synchronisation: 0 = no capacity flag raised (asserted)")
         if not args.no_cpu_baseline and world == 1:
             nf = min(args.cpu_frames, nb)

@@ -17,6 +17,7 @@
 #ifndef VSLAM_AMD_H
 #define VSLAM_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -289,6 +290,60 @@ int mo_dev_orb_detect_compute(mo_ctx*, const mo_orb_params*, const uint8_t* d_gr
 int mo_dev_match_pairs(mo_ctx*, const uint8_t* d_desc, const int32_t* d_counts, int cap, const int32_t* d_qf,
                        const int32_t* d_tf, int n_pairs, double ratio, int32_t* d_idx, int32_t* d_dist,
                        uint8_t* d_pass);
+
+/* ---- a frame SEQUENCE through the batched mode (stream.hip) ---------------------------------------------------------------------
+ * The reference's driver hands frames over one at a time (src/tests/tester_map.py:57-75 -> Tracker.process_frame, tracker.py:73-146).
+ * A caller that can look a few frames ahead gets the batched mode's rate from host frames: mo_stream cuts the sequence into chunks, runs
+ * every chunk as ONE mo_dev_frontend_batch call on chunk + 1 frames (the previous chunk's last frame is staged again in front, so every
+ * consecutive pair of the sequence is matched exactly once) and overlaps the upload of chunk i + 1 and the caller's handling of chunk
+ * i - 1 with the compute of chunk i (two lanes of pinned / device buffers, a copy stream beside the context's stream).  The sampling
+ * stream of a pair is keyed by its global index: poses equal those of a per-frame loop that passes mo_pair_params.pair_index.
+ *   mo_stream_submit   n <= chunk host frames (u8, rows of `stride` bytes, frames `frame_stride` bytes apart; 0 = dense): staged by a few
+ *                      host threads, uploaded and enqueued; returns without waiting.  At most two chunks may be in flight.
+ *   mo_stream_collect  waits for the OLDEST chunk in flight and describes its results: pointers into the lane's pinned host buffer,
+ *                      valid until the second submit after this collect.  MO_ERR_CAPACITY when a capacity flag was raised inside the
+ *                      chunk (r->flags, bits as in mo_dev_status; the results are still described). */
+typedef struct {
+    int32_t w, h, ch;          /* frames: u8, ch = 1 (gray) or 3 (BGR, converted on the device) */
+    int32_t chunk;             /* frames per batched call; the context needs max_batch >= chunk + 1 */
+    int32_t cap;               /* keypoint rows per frame */
+    int32_t detector;          /* MO_DETECT_ORB or MO_DETECT_GRID */
+    int32_t mode;              /* MO_MODE_TRACK (tracker.py:214-254 on every consecutive pair) or MO_MODE_INIT (initializer.py:67-120) */
+    double ratio, disp_frac, K[9], thr_px;
+    int32_t n_hyp;
+    uint64_t seed;
+    uint64_t pair_index_base;  /* global index of the sequence's first pair */
+    int32_t want_matches;      /* MO_MODE_TRACK: also return the knn lists (MO_MODE_INIT always does) */
+    int32_t want_points;       /* return the map points */
+} mo_stream_params;
+
+typedef struct {
+    int32_t n_frames, n_pairs;     /* frames of this chunk; pairs = n_frames - 1 for the first chunk, n_frames afterwards */
+    uint64_t first_frame;          /* global index of frame row 0 */
+    uint64_t first_pair;           /* global index of pair row 0: pair g = (frame g, frame g + 1) */
+    int32_t cap, flags;
+    int32_t prev_count;            /* keypoints of the frame in front of this chunk (the query frame of pair row 0 when first_pair < first_frame) */
+    const int32_t* counts;         /* [n_frames] */
+    const mo_keypoint* kps;        /* [n_frames][cap] */
+    const uint8_t* desc;           /* [n_frames][cap][32] */
+    const int32_t* sel_idx;        /* MO_MODE_TRACK: [n_pairs][cap][2] (queryIdx, trainIdx), the reference's order */
+    const int32_t* sel_dist;       /* [n_pairs][cap] */
+    const int32_t* sel_n;          /* [n_pairs] */
+    const double* pose;            /* [n_pairs][12] R then t (NaN: no model) */
+    const uint8_t* pose_mask;      /* [n_pairs][cap] recoverPose mask per QUERY keypoint */
+    const int32_t* n_points;       /* [n_pairs] */
+    const int32_t* match_idx;      /* [n_pairs][cap][2] or NULL */
+    const int32_t* match_dist;     /* [n_pairs][cap][2] or NULL */
+    const uint8_t* match_pass;     /* [n_pairs][cap] or NULL */
+    const float* points;           /* [n_pairs][cap][3] or NULL */
+} mo_stream_result;
+
+typedef struct mo_stream mo_stream;
+mo_stream* mo_stream_create(mo_ctx*, const mo_orb_params*, const mo_stream_params*);  /* NULL on failure: mo_last_error(ctx) */
+void mo_stream_destroy(mo_stream*);
+int mo_stream_submit(mo_stream*, const uint8_t* frames, int n, int stride, size_t frame_stride);
+int mo_stream_collect(mo_stream*, mo_stream_result*);
+const char* mo_stream_last_error(mo_stream*);
 
 /* ---- multi-GPU: the final map-point gather (SURVEY.md 8b mo_gather_map_points, 8e) --------------------------------------
  * One process per GPU, each with its own context; frames are sharded contiguously and nothing is exchanged on the data path.

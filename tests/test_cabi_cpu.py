@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header(tmp_path):
     import subprocess
     import vslam_amd as V
     structs = [("mo_batch_io", V.BatchIO), ("mo_orb_params", V.OrbParams), ("mo_frame_ref", V.FrameRef), ("mo_pair_params", V.PairParams),
-               ("mo_pair_out", V.PairOut)]
+               ("mo_pair_out", V.PairOut), ("mo_stream_params", V.StreamParams), ("mo_stream_result", V.StreamResult)]
     body = ""
     for cname, cls in structs:
         body += '  printf("%%zu\\n", sizeof(%s));\n' % cname

@@ -304,6 +304,20 @@ def test_example_frame_loop_runs(extra):
     assert (tx > 0.9).mean() > 0.6, tx
 
 
+@pytest.mark.parametrize("extra", [[], ["--grid"]])
+def test_example_frame_loop_batched_equals_per_frame(extra):
+    """run_frames.py --batch N (FrameStream: one batched device call per N frames) against the same sequence frame by frame: same
+    state, map size and number of poses, the initialisation pose and every tracked pose within rounding of the per-frame loop's (the
+    per-frame loop of the example does not count its pairs, so the sampling streams differ: 1e-4 rather than bit equality - the
+    bit-equal comparison with pair_index is tests/test_gpu_frame_api.py::test_frame_stream_equals_the_per_frame_loop)."""
+    mod = _run_frames_module()
+    s1, p1, m1 = mod.main(["--max-frames", "14"] + extra)
+    s2, p2, m2 = mod.main(["--max-frames", "14", "--batch", "5"] + extra)
+    assert s1 == s2 == "TRACKING" and m1 == m2 and len(p1) == len(p2) >= 10
+    for (Ra, ta), (Rb, tb) in zip(p1, p2):
+        assert np.abs(Ra - Rb).max() < 1e-3 and np.abs(np.ravel(ta) - np.ravel(tb)).max() < 2e-2
+
+
 def test_example_driver_reads_the_reference_config_and_real_frames(tmp_path, golden_dir):
     """run_frames.py --config <yaml> --frames <dir>: the keys of the reference's configs/monocular.yaml (camera, orb, matcher,
     max_frames) and a directory of real frames - tests/golden/gt_pairs/pair01 (two 478 x 850 (w x h) colour frames of the reference's video,

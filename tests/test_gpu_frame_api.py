@@ -232,3 +232,45 @@ def test_initialize_with_6000_matches_ratio_test_off():
     p1 = np.float32([k0.array[m.queryIdx][["x", "y"]].tolist() for m in put]); p2 = np.float32([k1.array[m.trainIdx][["x", "y"]].tolist() for m in put])
     o = G.init_two_view(p1, p2, Kc, thr_px=3.0, n_hyp=4096, seed=4096)
     assert ok and np.linalg.norm(R - o["R"]) < 1e-4 and np.linalg.norm(t - o["t"]) < 1e-4 and abs(len(pts) - o["n_good"]) <= 3 and len(pts) > 500
+
+
+@pytest.mark.parametrize("chunk,detector", [(4, "orb"), (7, "orb"), (5, "grid")])
+def test_frame_stream_equals_the_per_frame_loop(chunk, detector):
+    """vslam_amd.stream.FrameStream (mo_stream: chunks through mo_dev_frontend_batch, double-buffered upload, halo frame) against the
+    per-frame loop of the reference's driver (tester_map.py:57-75) through the single-frame API with pair_index = i: keypoints,
+    descriptors and kept tracking matches bit-identical, poses bit-identical (the sampler is keyed by the global pair index), for chunk
+    sizes that do and do not divide the sequence."""
+    import vslam_amd as V
+    from vslam_amd.stream import FrameStream
+    nfr = 18
+    frames = parallax_frames(nfr, seed=5, bg_step=3, fg_step=6)
+    grid = detector == "grid"
+    fs = FrameStream(K, chunk=chunk, n_features=2000, cap=2048, detector=V.DETECT_GRID if grid else V.DETECT_ORB, n_hyp=1024)
+    try:
+        got = list(fs.run(iter(frames)))
+    finally:
+        fs.close()
+    assert [g.index for g in got] == list(range(nfr)) and got[0].pair is None
+    ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
+    prm = V.orb_params(nfeatures=2000)
+    last = None
+    for i in range(nfr):
+        if grid:
+            xy, kept, d = ctx.grid_detect_compute(frames[i], prm, 2000)
+            k = np.zeros(len(kept), V.KP_DTYPE)
+            k["x"], k["y"], k["size"], k["angle"], k["class_id"] = xy[kept, 0], xy[kept, 1], 31, -1, -1
+        else:
+            (k, d), = ctx.orb_detect_compute(frames[i], prm)
+        g = got[i]
+        assert np.array_equal(g.keypoints, k) and np.array_equal(g.descriptors, d), i
+        if last is not None:
+            r = ctx.track_pair(last[0], last[1], k, d, 640, 480, K, n_hyp=1024, pair_index=i - 1)
+            p = g.pair
+            assert p["pair_index"] == i - 1
+            assert np.array_equal(p["sel"], r["sel"]) and np.array_equal(p["sel_dist"], r["sel_dist"]), i
+            assert p["ok"] == (len(r["sel"]) >= 8 and bool(np.isfinite(r["R"]).all()))
+            if p["ok"]:
+                assert np.array_equal(p["R"], r["R"]) and np.array_equal(p["t"], r["t"]), i
+                assert np.array_equal(p["inlier"], r["inlier"]) and p["n_inliers"] == r["n_inliers"], i
+        last = (k, d)
+    ctx.close()

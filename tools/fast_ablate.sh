@@ -19,16 +19,26 @@ assert stage_end in s
 if v == "s1":
     s = s.replace(stage_end, stage_end + "    if (P.nlevels > 0) return;\n", 1)
 elif v == "s2a":
-    s = s.replace("                score_pair(wq[2 * lane], wq[2 * lane + 1], true, true);", "                asm volatile(\"\" :: \"v\"(wq[2 * lane]));")
-    s = s.replace("            score_pair(wq[i0], wq[i1], 2 * lane < qn, 2 * lane + 1 < qn);", "            asm volatile(\"\" :: \"v\"(wq[i0] + wq[i1]));")
-    s = s.replace("    // ---- 3. NMS + border filter on the listed corners", "    if (P.nlevels > 0) return;\n    // ---- 3. NMS + border filter on the listed corners", 1)
+    for a, b in (("score_one(wq[qd + lane], 0, true);", 'asm volatile("" :: "v"(wq[qd + lane]));'),
+                 ("score_one(wq[FAST_STACK - 1 - qb - lane], 0xFF, true);", 'asm volatile("" :: "v"(wq[FAST_STACK - 1 - qb - lane]));'),
+                 ("if (qd > 0) score_one(wq[min(lane, qd - 1)], 0, lane < qd);", 'if (qd > 0) asm volatile("" :: "v"(wq[min(lane, qd - 1)]));'),
+                 ("if (qb > 0) score_one(wq[FAST_STACK - 1 - min(lane, qb - 1)], 0xFF, lane < qb);", 'if (qb > 0) asm volatile("" :: "v"(wq[FAST_STACK - 1 - min(lane, qb - 1)]));')):
+        assert a in s, a
+        s = s.replace(a, b)
+    a = "    // ---- 3. NMS + border filter on the listed corners"
+    assert a in s
+    s = s.replace(a, "    if (P.nlevels > 0) return;\n" + a, 1)
 elif v == "s2":
-    s = s.replace("    // ---- 3. NMS + border filter on the listed corners", "    if (P.nlevels > 0) return;\n    // ---- 3. NMS + border filter on the listed corners", 1)
+    a = "    // ---- 3. NMS + border filter on the listed corners"
+    assert a in s
+    s = s.replace(a, "    if (P.nlevels > 0) return;\n" + a, 1)
 elif v == "s3":
-    s = s.replace("    const int nwords = (nitems + 31) >> 5, wpt = (nwords + 255) >> 8;  // wpt <= 2", "    if (P.nlevels > 0) return;\n    const int nwords = (nitems + 31) >> 5, wpt = (nwords + 255) >> 8;  // wpt <= 2", 1)
+    a = "    const int nwords = (nitems + 31) >> 5, wpt = (nwords + NT - 1) / NT;  // wpt <= 2"
+    assert a in s
+    s = s.replace(a, "    if (P.nlevels > 0) return;\n" + a, 1)
 open(f, "w").write(s)
 PY
-  make -C "$tmp/visual-slam_amd/csrc" -j8 >/dev/null 2>&1
+  make -C "$tmp/visual-slam_amd/csrc" -j8 2>&1 | grep -E "error" -A3 | head -5 || true
   cp "$tmp/visual-slam_amd/libvslam_amd.so" "$root/visual-slam_amd/variants/libfast_$v.so"
   rm -rf "$tmp"; echo built $v
 done

@@ -66,10 +66,12 @@ int mo_run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int
     else mo_stage_begin(c);
     // margins of the levels nothing in this pipeline reads (see orb_launch_blur / orb_launch_pyramid)
     const int blur_margin = (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
+    // (one frame of a host call: the finest level's FAST + selection on a second stream beside the pyramid and the other levels was
+    //  measured in round 4 - no gain, level 1's chain is as long as level 0's: profiles/r04_ab_single_split.txt)
     if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels, pyr_margin))) return rc;
     mo_stage_mark(c, "pyramid");
     // the Gaussian blur only depends on the pyramid: in line, right behind it (an aux-stream fork beside FAST + selection gained <= 1 %
-    // in rounds 1 - 2 and was retired: profiles/r02_ab_serial_blur.txt)
+    // in the BATCHED mode in rounds 1 - 2 and was retired there: profiles/r02_ab_serial_blur.txt)
     if (d_desc) {
         if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin))) return rc;
         mo_stage_mark(c, "blur");

@@ -73,8 +73,6 @@ struct mo_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int match_mode = 0;        // VSLAM_AMD_MATCHER: 0 default (XOR + popcount, train tiles through LDS), 1 "mfma" opt-in matrix-core matcher
     int poison = -1;           // mo_dbg_set_poison (tests): fill the pyramid buffers with that byte before every extraction
-    hipStream_t aux_stream = nullptr;           // single-frame extraction: the coarse levels' chain beside the finest level's (frame_api.hip)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     // plan (rebuilt when w, h or the ORB parameters change)
@@ -123,6 +121,7 @@ struct mo_ctx {
     uint2* d_match_part = nullptr; size_t match_part_bytes = 0;  // per-slice keys of a split k_match_lds launch
     // two-view work buffers
     void* d_tv = nullptr; size_t tv_bytes = 0;
+    float* d_stream_pts = nullptr; size_t stream_pts_bytes = 0;  // mo_stream: map-point scratch of chunks whose caller does not want them
     uint32_t* d_track_keys = nullptr; size_t track_keys_bytes = 0;  // k_track_select: key arrays of frames too large for LDS
     // generic temp
     void* d_tmp = nullptr; size_t tmp_bytes = 0;

@@ -62,8 +62,6 @@ extern "C" mo_ctx* mo_create(int device, int max_w, int max_h, int max_batch) {
     // scope); the default system-scope fence of an event record writes the L2 back and cost 6 - 17 us of idle GPU at every stage mark
     // (kernel trace: gaps only where an event sits between two kernels), 0.06 ms of a 2.2 ms step (profiles/r02_ab_event_fence.txt).
     const unsigned evf = (unsigned)hipEventDisableSystemFence;
-    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming | evf);
-    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming | evf);
     for (TimingSet& t : c->tsets)
         for (int i = 0; i <= MO_NSTAGES; i++) hipEventCreateWithFlags(&t.ev[i], evf);
     if (hipMalloc((void**)&c->d_flags, 8 * sizeof(int)) != hipSuccess) {
@@ -100,14 +98,12 @@ extern "C" void mo_destroy(mo_ctx* c) {
     free_plan_buffers(c);
     void* bufs[] = {c->d_in, c->d_gray, c->d_flags, c->d_kps, c->d_desc, c->d_counts, c->d_mq, c->d_mt,
                     c->d_midx, c->d_mdist, c->d_mpass, c->d_match_part, c->d_tv, c->d_tmp, c->d_pair_frames, c->d_dtodo, c->d_comm_cnt,
-                    c->d_slot_kps, c->d_slot_desc, c->d_slot_cnt, c->d_slot_ids, c->d_track_keys};
+                    c->d_slot_kps, c->d_slot_desc, c->d_slot_cnt, c->d_slot_ids, c->d_track_keys, c->d_stream_pts};
     for (void* b : bufs) if (b) hipFree(b);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (TimingSet& t : c->tsets) {
         for (int i = 0; i <= MO_NSTAGES; i++) if (t.ev[i]) hipEventDestroy(t.ev[i]);
     }
-    if (c->ev_fork) { hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
-    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }

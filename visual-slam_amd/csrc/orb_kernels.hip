@@ -18,11 +18,6 @@
 #include <cstring>
 
 #include "common.h"
-// threads of a k_select workgroup (the replay's partition passes, the Harris groups and the strip gather are dealt over its wavefronts)
-#ifndef SEL_THREADS
-#define SEL_THREADS 256
-#endif
-#define WG_THREADS SEL_THREADS
 #include "select_replay.h"
 
 __constant__ __attribute__((aligned(16))) int8_t c_pattern[256 * 4] = {
@@ -910,7 +905,11 @@ __device__ __forceinline__ size_t sel_need_bytes(int n, int rec_bytes) {
 }
 
 #define HG 8                       // lanes per keypoint in the Harris phase
-#define HG_GROUPS (SEL_THREADS / HG)
+// threads of a k_select workgroup (the replay's partition passes, the Harris groups and the strip gather are dealt over its wavefronts):
+// 256 in the batched mode (3 workgroups per CU; 512 / 1024 threads: 0.192 -> 0.240 / 0.418 ms per 256 frames), 1024 for one or two
+// frames, where the chip is empty and the call waits for the finest levels' workgroups (91 -> 73 us; profiles/r04_ab_select_threads.txt)
+#define SEL_THREADS 256
+#define SEL_THREADS_LATENCY 1024
 
 // Harris response of one keypoint by a group of HG = 8 lanes (same integer sums as harris_response, hence the same float):
 // the 9x9 window is fetched as 9 rows x 3 aligned dwords (27 loads dealt over the 8 lanes: 12 cache-line accesses per keypoint;
@@ -963,12 +962,12 @@ __device__ __forceinline__ float harris_group(const uint32_t (&reg)[4], int x0, 
 
 // phase 2 of the selection: Harris on the pass-1 survivors (in their pass-1 order), retainBest(quota) replay, write-out;
 // all by the whole workgroup
-template <class PA, class PB>
+template <int NT, class PA, class PB>
 __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1,
                                               uint16_t* rpos, unsigned long long* bl, FinalKp* fin, int* fin_cnt_out,
-                                              int* flags, replay::WgScratch* ws) {
+                                              int* flags, replay::WgScratch<NT>* ws, uint32_t (*s_hw)[27] /* [NT / HG] group-private windows */) {
     const int tid = threadIdx.x;
-    __shared__ uint32_t s_hw[HG_GROUPS][27];
+    constexpr int HG_GROUPS = NT / HG;
     if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {  // block-uniform; a keypoint sits >= edge_threshold >= 4 columns inside its row
         const int grp = tid / HG, g = tid % HG;
         // HB keypoints per group and trip: all their window loads are issued before the first one is reduced - the phase is a
@@ -992,7 +991,7 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
             }
         }
     } else {
-        for (int i = tid; i < N1; i += SEL_THREADS) {
+        for (int i = tid; i < N1; i += NT) {
             uint32_t e = A[i];
             int x = e & 0xFFF, y = (e >> 12) & 0xFFF;
             float r = harris_response(img, lv.pitch, x, y);
@@ -1000,12 +999,12 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
         }
     }
     __syncthreads();
-    int N2 = replay::wg_retain_best<uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid, ws);
+    int N2 = replay::wg_retain_best<NT, uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid, ws);
     if (N2 > lv.fin_cap) {
         if (tid == 0) atomicOr(&flags[0], 1);
         N2 = lv.fin_cap;
     }
-    for (int i = tid; i < N2; i += SEL_THREADS) {
+    for (int i = tid; i < N2; i += NT) {
         uint64_t e = B[i];
         FinalKp k;
         k.x = (uint16_t)(e & 0xFFF);
@@ -1016,9 +1015,10 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
     if (tid == 0) *fin_cnt_out = N2;
 }
 
-// One workgroup (4 wavefronts) per (frame, level).  Gather, Harris, write-out and the partition passes of the two
+// One workgroup (NT / 64 wavefronts) per (frame, level).  Gather, Harris, write-out and the partition passes of the two
 // retainBest replays use all wavefronts (workgroup-parallel pairing partition, select_replay.h).
-__global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_select(Plan P, const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                                         const uint32_t* __restrict__ cand, const int* __restrict__ strip_cnt,
                                                         uint64_t* __restrict__ scratch, size_t scratch_stride,
                                                         FinalKp* __restrict__ fin_all, int* __restrict__ fin_cnt, int* flags,
@@ -1026,7 +1026,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     extern __shared__ __attribute__((aligned(16))) uint8_t s_buf[];  // buf_bytes (per launch: coarse levels get less) + the strip prefix table
     int* const s_pref = (int*)(s_buf + buf_bytes);  // [max strips of a level + 1] (sized by the launch: 1 KB at 640 x 480; a static 4 KB
                                                     // table for 4K frames cost every launch a workgroup per CU: 0.218 -> 0.303 ms)
-    __shared__ replay::WgScratch s_ws;
+    __shared__ replay::WgScratch<NT> s_ws;
+    __shared__ uint32_t s_hw[NT / HG][27];          // Harris windows, one per 8-lane group
     const int L = level0 + blockIdx.y, frame = blockIdx.x, tid = threadIdx.x;  // dispatch order: all frames of the finest level first
     if (desc_todo && frame == 0 && blockIdx.y == 0 && tid == 0) desc_todo[0] = 0;  // k_describe_tiles' list of left-over tiles (this call's)
     const LevelInfo lv = P.lv[L];
@@ -1036,7 +1037,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
         return;
     }
     const int* cnts = strip_cnt + (size_t)frame * P.strips_per_frame + lv.strip_base;
-    for (int s = tid; s < lv.nstrips; s += SEL_THREADS) s_pref[s + 1] = cnts[s];
+    for (int s = tid; s < lv.nstrips; s += NT) s_pref[s + 1] = cnts[s];
     __syncthreads();
     if (tid == 0) {
         s_pref[0] = 0;
@@ -1060,7 +1061,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
         // four strips per wavefront and trip: their first 64 records each are fetched together (a strip list is a dependent
         // round trip, and a level has up to 60 of them: 15 per wavefront one after the other were 12 us of the level-0 chain)
         const int lane = tid & 63, wv = tid >> 6;
-        constexpr int NW = SEL_THREADS / 64, GU = 4;
+        constexpr int NW = NT / 64, GU = 4;
         for (int s0 = wv; s0 < lv.nstrips; s0 += NW * GU) {  // wave-uniform
             uint32_t v[GU];
             int b[GU], n[GU];
@@ -1083,8 +1084,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     }
     __syncthreads();
     // pass 1: retainBest(2 * quota) on the FAST score
-    const int N1 = a_lds ? replay::wg_retain_best<uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, tid, &s_ws)
-                         : replay::wg_retain_best<uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, tid, &s_ws);
+    const int N1 = a_lds ? replay::wg_retain_best<NT, uint32_t>(s_A, N, 2 * lv.quota, P.select_order, a_rpos, a_bl, tid, &s_ws)
+                         : replay::wg_retain_best<NT, uint32_t>(gA, N, 2 * lv.quota, P.select_order, g_rpos, g_bl, tid, &s_ws);
     // the Harris records (and their rpos / ballots) go behind the surviving FAST records when both fit the window
     const size_t b_off = a_lds ? (((size_t)N1 * 4 + 15) & ~(size_t)15) : 0;
     const bool b_lds = b_off + sel_need_bytes(N1, 8) <= (size_t)buf_bytes;
@@ -1093,10 +1094,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(Plan P, const uint8_t* _
     unsigned long long* b_bl = (unsigned long long*)((uint8_t*)b_rpos + ((((size_t)N1 / 2 + 1) * 2 + 7) & ~(size_t)7));
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
-    if (a_lds && b_lds) select_harris(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws);
-    else if (a_lds) select_harris(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws);
-    else if (b_lds) select_harris(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws);
-    else select_harris(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws);
+    if (a_lds && b_lds) select_harris<NT>(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
+    else if (a_lds) select_harris<NT>(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
+    else if (b_lds) select_harris<NT>(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
+    else select_harris<NT>(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
 }
 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, int level_hi) {
@@ -1108,20 +1109,26 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo,
     int max_strips = 1;
     for (int L = 0; L < P.nlevels; L++) max_strips = std::max(max_strips, P.lv[L].nstrips);
     const size_t pref_bytes = (((size_t)max_strips + 1) * sizeof(int) + 15) & ~(size_t)15;
+    const size_t attr_bytes = SEL_BUF_BYTES + ((((size_t)SEL_MAXSTRIPS + 1) * sizeof(int) + 15) & ~(size_t)15);
     if (!(c->lds_attr_done & 16u)) {
-        HIPCHK(c, hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      SEL_BUF_BYTES + ((((size_t)SEL_MAXSTRIPS + 1) * sizeof(int) + 15) & ~(size_t)15)));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_select<SEL_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr_bytes));
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_select<SEL_THREADS_LATENCY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attr_bytes));
         c->lds_attr_done |= 16u;
     }
-    // One launch, every workgroup with the full LDS record window (4 resident per CU), levels in dispatch order from fine to
-    // coarse: the replays are latency-bound single wavefronts whose length grows with the candidate count, so the long
-    // level-0 tasks start first and the short coarse-level tasks fill the slots that free up (longest-task-first packing).
-    // A level that outgrows the window falls back to its HBM scratch slot (same code, slower).  Round 2 re-measured the
-    // alternatives on MI355X: a second launch for the coarse levels with a smaller window (8 - 24 KB, more workgroups per CU):
-    // 0.23 - 0.25 ms against 0.20 ms; selecting the finest level on the auxiliary stream beside FAST of the others: no gain
-    // (the coarse levels alone take 0.19 ms: the kernel is bound by the sum of the replays, not by the finest level).
-    hipLaunchKernelGGL(k_select, dim3(batch, level_hi - level_lo), dim3(SEL_THREADS), SEL_BUF_BYTES + pref_bytes, c->stream, P, d_gray, c->d_pyr, c->d_cand,
-                       c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES, c->d_dtodo);
+    // One launch, every workgroup with the full LDS record window (3 resident per CU at 256 threads), levels in dispatch order from fine
+    // to coarse: the replays are latency-bound chains whose length grows with the candidate count, so the long level-0 tasks start first
+    // and the short coarse-level tasks fill the slots that free up (longest-task-first packing).  A level that outgrows the window falls
+    // back to its HBM scratch slot (same code, slower).  Round 2 re-measured the alternatives on MI355X: a second launch for the coarse
+    // levels with a smaller window (8 - 24 KB, more workgroups per CU): 0.23 - 0.25 ms against 0.20 ms; selecting the finest level on the
+    // auxiliary stream beside FAST of the others: no gain (the coarse levels alone take 0.19 ms: the kernel is bound by the sum of the
+    // replays, not by the finest level).  One or two frames (the single-frame host calls): 16 wavefronts per workgroup.
+    const dim3 grid(batch, level_hi - level_lo);
+    if (batch <= 2)
+        hipLaunchKernelGGL(k_select<SEL_THREADS_LATENCY>, grid, dim3(SEL_THREADS_LATENCY), SEL_BUF_BYTES + pref_bytes, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+                           c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES, c->d_dtodo);
+    else
+        hipLaunchKernelGGL(k_select<SEL_THREADS>, grid, dim3(SEL_THREADS), SEL_BUF_BYTES + pref_bytes, c->stream, P, d_gray, c->d_pyr, c->d_cand,
+                           c->d_strip_cnt, c->d_scratch, c->scratch_stride, c->d_fin, c->d_fin_cnt, c->flags_cur, level_lo, SEL_BUF_BYTES, c->d_dtodo);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
 }
@@ -1129,10 +1136,10 @@ int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo,
 // probe for the parity tests: retainBest on a bare float response array (u64 record path, HBM-resident records)
 __global__ __launch_bounds__(SEL_THREADS) void k_retain_probe(const float* resp, int n, int n_points, int order, uint64_t* rec,
                                                               uint16_t* rpos, unsigned long long* bl, int32_t* out, int* nout) {
-    __shared__ replay::WgScratch s_ws;
+    __shared__ replay::WgScratch<SEL_THREADS> s_ws;
     for (int i = threadIdx.x; i < n; i += SEL_THREADS) rec[i] = ((uint64_t)__float_as_uint(resp[i]) << 32) | (uint32_t)i;
     __syncthreads();
-    int keep = replay::wg_retain_best<uint64_t>(rec, n, n_points, order, rpos, bl, threadIdx.x, &s_ws);
+    int keep = replay::wg_retain_best<SEL_THREADS, uint64_t>(rec, n, n_points, order, rpos, bl, threadIdx.x, &s_ws);
     __syncthreads();
     for (int i = threadIdx.x; i < keep; i += SEL_THREADS) out[i] = (int32_t)(rec[i] & 0xFFFFFFFFu);
     if (threadIdx.x == 0) *nout = keep;

@@ -563,32 +563,30 @@ __device__ __forceinline__ int wave_retain_best(P a, int n, int n_points, int or
 }
 
 // ================================================================ workgroup-parallel replay (4 wavefronts) ==========
-// The same pairing partition with the 256-element trips dealt round-robin to the WG_WAVES wavefronts of the workgroup.
+// The same pairing partition with the 256-element trips dealt round-robin to the NT / 64 wavefronts of the workgroup.
 // Trip t (elements lo + 256 t ..) needs the number of left / right stoppers in the trips before it: pass 1 leaves the
 // per-trip counts in LDS, one wavefront turns them into exclusive prefix sums (<= 64 trips: one shuffle scan), passes 2
 // and 3 then run independently per trip.  K and the cut are combined over the wavefronts (positions grow with the trip
 // number, so the minimum over the wavefronts' first hits is the global first hit).  All 256 threads call these functions
 // convergently; every branch below depends only on values that are identical in all threads.
-#ifndef WG_THREADS
-#define WG_THREADS 256
-#endif
-#define WG_WAVES (WG_THREADS / 64)
-struct WgScratch {
+// NT = threads of the workgroup (k_select runs 256 in the batched mode - 3 workgroups per CU - and 1024 for one or two frames, where
+// nothing else competes for the CU and the long first partition rounds of a level are what the call waits for)
+template <int NT> struct WgScratch {
     int cl[64], cr[64], pl[65], pr[65];
-    int k[WG_WAVES], nl[WG_WAVES], sr[WG_WAVES];
+    int k[NT / 64], nl[NT / 64], sr[NT / 64];
     int cut;
 };
 #define WG_PARTITION_MIN 384     // shorter ranges: one wavefront does it alone (saves the barriers)
 #define WG_PARTITION_MAX 16384   // 64 trips: what one shuffle scan covers
 
-template <class T, class P, class FL, class FR>
+template <int NT, class T, class P, class FL, class FR>
 __device__ __forceinline__ int wg_pair_partition(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
-                                                 int tid, WgScratch* ws, int* total_r) {
+                                                 int tid, WgScratch<NT>* ws, int* total_r) {
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int ntrip = (hi - lo + 64 * RP_EPL - 1) / (64 * RP_EPL);
     // pass 1: ballots of the left stoppers (kept for pass 3) and per-trip stopper counts
-    for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
+    for (int t = wv; t < ntrip; t += NT / 64) {
         const int c0 = lo + t * 64 * RP_EPL;
         T v[RP_EPL];
 #pragma unroll
@@ -624,7 +622,7 @@ __device__ __forceinline__ int wg_pair_partition(P a, int lo, int hi, FL stopL, 
     // pass 2: which stoppers swap, where their partners are, K and the cut
     int Kw = 0, minNL = 0x7FFFFFFF, minSR = 0x7FFFFFFF;
     bool foundNL = false, foundSR = false;
-    for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
+    for (int t = wv; t < ntrip; t += NT / 64) {
         const int c0 = lo + t * 64 * RP_EPL;
         const int baseL = ws->pl[t], baseR = ws->pr[t];
         T v[RP_EPL];
@@ -671,9 +669,9 @@ __device__ __forceinline__ int wg_pair_partition(P a, int lo, int hi, FL stopL, 
     __syncthreads();
     int K = 0, cut = 0x7FFFFFFF;
 #pragma unroll
-    for (int q = 0; q < WG_WAVES; q++) { K += ws->k[q]; cut = min(cut, min(ws->nl[q], ws->sr[q])); }
+    for (int q = 0; q < NT / 64; q++) { K += ws->k[q]; cut = min(cut, min(ws->nl[q], ws->sr[q])); }
     // pass 3: the swaps (a left stopper of rank <= K with the right stopper of the same rank)
-    for (int t = wv; t < ntrip; t += WG_THREADS / 64) {
+    for (int t = wv; t < ntrip; t += NT / 64) {
         const int baseL = ws->pl[t];
         if (baseL >= K) break;
         const int c0 = lo + t * 64 * RP_EPL;
@@ -705,11 +703,11 @@ __device__ __forceinline__ int wg_pair_partition(P a, int lo, int hi, FL stopL, 
 }
 
 // one partition step for the whole workgroup: cooperative when the range is long enough, else wavefront 0 alone
-template <class T, class P, class FL, class FR>
+template <int NT, class T, class P, class FL, class FR>
 __device__ __forceinline__ int wg_partition_step(P a, int lo, int hi, FL stopL, FR stopR, uint16_t* rpos, unsigned long long* bl,
-                                                 int tid, WgScratch* ws, int* total_r) {
+                                                 int tid, WgScratch<NT>* ws, int* total_r) {
     const int n = hi - lo;
-    if (n >= WG_PARTITION_MIN && n <= WG_PARTITION_MAX) return wg_pair_partition<T>(a, lo, hi, stopL, stopR, rpos, bl, tid, ws, total_r);
+    if (n >= WG_PARTITION_MIN && n <= WG_PARTITION_MAX) return wg_pair_partition<NT, T>(a, lo, hi, stopL, stopR, rpos, bl, tid, ws, total_r);
     if (tid < 64) {
         int tr = 0;
         int c = wave_pair_partition<T>(a, lo, hi, stopL, stopR, rpos, bl, tid, &tr);
@@ -722,9 +720,9 @@ __device__ __forceinline__ int wg_partition_step(P a, int lo, int hi, FL stopL, 
     return c;
 }
 
-template <class T, class P>
+template <int NT, class T, class P>
 __device__ __forceinline__ void wg_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int tid,
-                                                  WgScratch* ws) {
+                                                  WgScratch<NT>* ws) {
     typedef Rec<T> R;
     if (first == last || nth == last) return;
     int depth = (31 - __clz(last - first)) * 2;
@@ -744,7 +742,7 @@ __device__ __forceinline__ void wg_ls_nth_element(P a, int first, int nth, int l
         if (tid == 0) ls_move_median_to_first<T>(a, first, first + 1, mid, last - 1);
         __syncthreads();
         const T pv = a[first];
-        int cut = wg_partition_step<T>(
+        int cut = wg_partition_step<NT, T>(
             a, first + 1, last, [pv](T v) { return !R::gt(v, pv); }, [pv](T v) { return !R::gt(pv, v); }, rpos, bl, tid, ws,
             (int*)nullptr);
         if (cut <= nth) first = cut;
@@ -754,10 +752,10 @@ __device__ __forceinline__ void wg_ls_nth_element(P a, int first, int nth, int l
     __syncthreads();
 }
 
-// retainBest for a 256-thread workgroup, all threads convergent; every thread returns the same count
-template <class T, class P>
+// retainBest for a workgroup of NT threads, all threads convergent; every thread returns the same count
+template <int NT, class T, class P>
 __device__ __forceinline__ int wg_retain_best(P a, int n, int n_points, int order, uint16_t* rpos, unsigned long long* bl, int tid,
-                                              WgScratch* ws) {
+                                              WgScratch<NT>* ws) {
     typedef Rec<T> R;
     if (n_points < 0 || n <= n_points) return n;
     if (n_points == 0) return 0;
@@ -765,7 +763,7 @@ __device__ __forceinline__ int wg_retain_best(P a, int n, int n_points, int orde
         if (tid == 0) ms_nth_element<T>(a, 0, n_points - 1, n);
         __syncthreads();
     } else {
-        wg_ls_nth_element<T>(a, 0, n_points - 1, n, rpos, bl, tid, ws);
+        wg_ls_nth_element<NT, T>(a, 0, n_points - 1, n, rpos, bl, tid, ws);
     }
     const T amb = a[n_points - 1];
     const int tail = n - n_points;
@@ -777,7 +775,7 @@ __device__ __forceinline__ int wg_retain_best(P a, int n, int n_points, int orde
         return n_points + keep;
     }
     int total_true = 0;
-    wg_partition_step<T>(
+    wg_partition_step<NT, T>(
         a, n_points, n, [amb](T v) { return !R::ge(v, amb); }, [amb](T v) { return R::ge(v, amb); }, rpos, bl, tid, ws,
         &total_true);
     return n_points + total_true;

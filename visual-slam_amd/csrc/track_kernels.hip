@@ -19,6 +19,7 @@
 
 #define TS_BLOCK 256
 #define TS_KEY_BITS 23
+#define TS_UNROLL 4
 #define TS_LDS_CAP 6000   // records whose two key arrays fit the default 48 KB of dynamic LDS
 
 __device__ __forceinline__ void ts_wave_sync() {
@@ -38,8 +39,8 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
     extern __shared__ uint32_t s_dyn[];  // [cap] keys in query order, then [cap] kept keys by rank (when gkeys is null)
     __shared__ int s_hist[320];          // survivors per distance (257 bins, zero-padded), then their exclusive prefix
     __shared__ int s_bin[260];           // running placement count per distance
-    __shared__ int s_w[TS_BLOCK / 64];
-    __shared__ int s_base, s_med[2];
+    __shared__ int s_w4[TS_UNROLL][TS_BLOCK / 64];
+    __shared__ int s_med[2];
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int fq = qf ? qf[pair] : pair, ft = tf ? tf[pair] : pair + 1;
     const int nq = min(counts[fq], cap);
@@ -51,33 +52,54 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
     uint32_t* keys = gkeys ? gkeys + (size_t)pair * 2 * cap : s_dyn;
     uint32_t* sorted = keys + cap;
     for (int b = tid; b < 320; b += TS_BLOCK) s_hist[b] = 0;
-    if (tid == 0) s_base = 0;
     __syncthreads();
-    // 1. ratio-test survivors within the displacement limit, compacted in query order; histogram of their distances
-    for (int b0 = 0; b0 < nq; b0 += TS_BLOCK) {
-        const int i = b0 + tid;
-        bool ok = i < nq && pass[i];
-        int d = 0;
-        if (ok) {
-            const int j = idx[2 * i];
-            const double dx = (double)k2[j].x - (double)k1[i].x, dy = (double)k2[j].y - (double)k1[i].y;
-            ok = sqrt(dx * dx + dy * dy) <= max_disp;
-            d = min(max(dst[2 * i], 0), 256);
+    // 1. ratio-test survivors within the displacement limit, compacted in query order; histogram of their distances.  TS_UNROLL x 256
+    //    queries per trip: the (pass, knn index, distance, both keypoints) loads of all of a thread's queries are in flight together -
+    //    one pair of 2000 queries waited for eight dependent load chains in a row before (22 us for this kernel alone).
+    int n_run = 0;
+    for (int b0 = 0; b0 < nq; b0 += TS_BLOCK * TS_UNROLL) {
+        bool ok[TS_UNROLL];
+        int d[TS_UNROLL], j[TS_UNROLL];
+        float x1[TS_UNROLL], y1[TS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TS_UNROLL; u++) {
+            const int i = b0 + u * TS_BLOCK + tid;
+            ok[u] = i < nq && pass[i];
+            j[u] = i < nq ? idx[2 * i] : 0;
+            d[u] = i < nq ? dst[2 * i] : 0;
+            x1[u] = i < nq ? k1[i].x : 0.f;
+            y1[u] = i < nq ? k1[i].y : 0.f;
         }
-        const unsigned long long bal = __ballot(ok);
-        if (lane == 0) s_w[wv] = __popcll(bal);
-        __syncthreads();
-        int off = s_base;
-        for (int k = 0; k < wv; k++) off += s_w[k];
-        if (ok) {
-            keys[off + __popcll(bal & ((1ull << lane) - 1ull))] = ((uint32_t)d << TS_KEY_BITS) | (uint32_t)i;
-            atomicAdd(&s_hist[d], 1);
+#pragma unroll
+        for (int u = 0; u < TS_UNROLL; u++) {
+            if (ok[u]) {
+                const mo_keypoint* kb = k2 + max(j[u], 0);
+                const double dx = (double)kb->x - (double)x1[u], dy = (double)kb->y - (double)y1[u];
+                ok[u] = sqrt(dx * dx + dy * dy) <= max_disp;
+                d[u] = min(max(d[u], 0), 256);
+            }
+        }
+        unsigned long long bal[TS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TS_UNROLL; u++) {
+            bal[u] = __ballot(ok[u]);
+            if (lane == 0) s_w4[u][wv] = __popcll(bal[u]);
         }
         __syncthreads();
-        if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        __syncthreads();
+        int off = n_run;  // survivors of the earlier trips, then of the earlier sub-rows and wavefronts of this one (query order)
+#pragma unroll
+        for (int u = 0; u < TS_UNROLL; u++) {
+            int mine = off;
+            for (int k = 0; k < TS_BLOCK / 64; k++) { if (k < wv) mine += s_w4[u][k]; off += s_w4[u][k]; }
+            if (ok[u]) {
+                keys[mine + __popcll(bal[u] & ((1ull << lane) - 1ull))] = ((uint32_t)d[u] << TS_KEY_BITS) | (uint32_t)(b0 + u * TS_BLOCK + tid);
+                atomicAdd(&s_hist[d[u]], 1);
+            }
+        }
+        n_run = off;
+        __syncthreads();  // (s_w4 is rewritten by the next trip)
     }
-    const int n = s_base;
+    const int n = n_run;
     // 2. exclusive prefix of the histogram (one wavefront, five bins per lane)
     if (wv == 0) {
         int v[5], sum = 0;

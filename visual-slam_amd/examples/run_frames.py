@@ -18,7 +18,12 @@ Inputs:
                       [N, H, W, 3] (BGR like cv2).  Frames are undistorted on the device when a distortion coefficient is non-zero
                       (run_video.py:145-149) and converted to gray on the device.  Without it: a synthetic sequence (a camera
                       translating past a two-depth scene), so the drop-in can be exercised end to end without cv2 or a video file.
-Usage: python visual-slam_amd/examples/run_frames.py [--config cfg.yaml] [--frames dir|file] [--max-frames 30] [--grid] [--python-filters]
+    --batch N         the same sequence through vslam_amd.stream.FrameStream: frames are gathered into chunks of N and every chunk is
+                      ONE batched device call (upload of the next chunk and the handling of the previous one overlapped with the
+                      compute); the first two frames still initialise the map through MapInitializer, every later frame takes its
+                      tracking result (against the previous frame) from the stream.  Same keypoints, descriptors, kept matches and
+                      poses as the per-frame loop - at the batched mode's rate.
+Usage: python visual-slam_amd/examples/run_frames.py [--config cfg.yaml] [--frames dir|file] [--max-frames 30] [--grid] [--python-filters] [--batch 64]
 """
 import argparse
 import os
@@ -108,6 +113,7 @@ def main(argv=None):
     ap.add_argument("--max-frames", type=int, default=30, help="frames of the synthetic sequence / cap on the input (0 = config's max_frames)")
     ap.add_argument("--grid", action="store_true", help="extract_features(distributed=True), the path Tracker.process_frame takes")
     ap.add_argument("--python-filters", action="store_true", help="tracking step through the per-method API (Python filter loops)")
+    ap.add_argument("--batch", type=int, default=0, help="N > 0: the sequence through FrameStream in chunks of N frames (one batched device call each)")
     args = ap.parse_args(argv)
     cfg, K, D = load_config(args.config)
     orb, mt = cfg["orb"], cfg["matcher"]
@@ -120,6 +126,8 @@ def main(argv=None):
     source = frames_from(args.frames) if args.frames else synthetic_sequence(limit if limit < 10 ** 9 else 30)
     state, last, poses, n_map, n_seen = "NOT_INITIALIZED", None, [], 0, 0
     t0 = time.perf_counter()
+    if args.batch > 0:
+        return run_batched(args, cfg, K, D, orb, mt, initializer, source, limit, skip, t0)
     for idx, frame in enumerate(source):
         if n_seen >= limit:
             break
@@ -166,6 +174,67 @@ def main(argv=None):
     print("%d frames in %.2f s (%.1f frames/s through the Python drop-in classes), state %s, %d poses"
           % (n_seen, dt, n_seen / max(dt, 1e-9), state, len(poses)))
     return state, poses, n_map
+
+
+def run_batched(args, cfg, K, D, orb, mt, initializer, source, limit, skip, t0):
+    """--batch N: the frame loop above with the extraction and the tracking step of EVERY frame taken from FrameStream (one batched
+    device call per N frames).  Initialisation (the first frame pair that yields a map) goes through MapInitializer on the streamed
+    keypoints / descriptors, exactly as Tracker does (tracker.py:162,168-170)."""
+    import vslam_amd as V
+    from orbslam2.types import KeyPointSeq
+    from vslam_amd.stream import FrameStream
+
+    def selected():
+        seen = 0
+        for idx, frame in enumerate(source):
+            if seen >= limit:
+                return
+            if skip and idx % (skip + 1) != 0:
+                continue
+            seen += 1
+            yield geom.undistort_image(frame, K, D) if np.any(D) else frame
+    frames = selected()
+    first = next(frames, None)
+    if first is None:
+        return "NOT_INITIALIZED", [], 0
+    h, w = first.shape[:2]
+    prm = V.orb_params(nfeatures=orb["n_features"], scale_factor=orb["scale_factor"], nlevels=orb["n_levels"], fast_threshold=orb["min_threshold"])
+    fs = FrameStream(K, width=w, height=h, channels=3 if first.ndim == 3 else 1, chunk=args.batch, prm=prm,
+                     detector=V.DETECT_GRID if args.grid else V.DETECT_ORB, ratio=mt["ratio_threshold"], disp_frac=0.02, thr_px=1.0)
+    matcher = DescriptorMatcher(mt["matcher_type"], ratio_threshold=mt["ratio_threshold"])
+    kept = {0: first}   # (frames the initialiser may still want: the first one, and the one being initialised against)
+
+    def chain():
+        yield first
+        for i, f in enumerate(frames, 1):
+            if state[0] == "NOT_INITIALIZED":
+                kept[i] = f
+            yield f
+    state, poses, n_map, n_seen = ["NOT_INITIALIZED"], [], 0, 0
+    try:
+        for r in fs.run(chain()):
+            n_seen += 1
+            kps, desc = KeyPointSeq(r.keypoints), r.descriptors
+            if state[0] == "NOT_INITIALIZED":
+                if initializer.first_frame_keypoints is None:
+                    initializer.set_first_frame(kps, desc, kept[r.index])
+                else:
+                    ok, R, t, pts, matches = initializer.initialize(kps, desc, matcher, kept.get(r.index, first))
+                    if ok:
+                        state[0], n_map = "TRACKING", len(pts)
+                        kept.clear()
+                        poses.append((R, t))
+                        print("frame %d: initialised, %d map points, t = %s" % (r.index, n_map, np.round(t.ravel(), 3)))
+            elif r.pair is not None and r.pair["ok"]:
+                poses.append((r.pair["R"], r.pair["t"]))
+                if r.index % 5 == 0:
+                    print("frame %d: %d pose inliers, t = %s" % (r.index, int(r.pair["inlier"].sum()), np.round(r.pair["t"].ravel(), 3)))
+    finally:
+        fs.close()
+    dt = time.perf_counter() - t0
+    print("%d frames in %.2f s (%.1f frames/s through FrameStream, chunks of %d), state %s, %d poses"
+          % (n_seen, dt, n_seen / max(dt, 1e-9), args.batch, state[0], len(poses)))
+    return state[0], poses, n_map
 
 
 if __name__ == "__main__":

@@ -69,6 +69,21 @@ class PairOut(C.Structure):
                 ("n1", C.c_int32), ("n2", C.c_int32), ("token1", C.c_uint64), ("token2", C.c_uint64)]
 
 
+class StreamParams(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("ch", C.c_int32), ("chunk", C.c_int32), ("cap", C.c_int32), ("detector", C.c_int32),
+                ("mode", C.c_int32), ("ratio", C.c_double), ("disp_frac", C.c_double), ("K", C.c_double * 9), ("thr_px", C.c_double),
+                ("n_hyp", C.c_int32), ("seed", C.c_uint64), ("pair_index_base", C.c_uint64), ("want_matches", C.c_int32),
+                ("want_points", C.c_int32)]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_pairs", C.c_int32), ("first_frame", C.c_uint64), ("first_pair", C.c_uint64), ("cap", C.c_int32),
+                ("flags", C.c_int32), ("prev_count", C.c_int32), ("counts", C.c_void_p), ("kps", C.c_void_p), ("desc", C.c_void_p),
+                ("sel_idx", C.c_void_p), ("sel_dist", C.c_void_p), ("sel_n", C.c_void_p), ("pose", C.c_void_p), ("pose_mask", C.c_void_p),
+                ("n_points", C.c_void_p), ("match_idx", C.c_void_p), ("match_dist", C.c_void_p), ("match_pass", C.c_void_p),
+                ("points", C.c_void_p)]
+
+
 MODE_INIT, MODE_TRACK, MODE_KEYFRAME = 0, 1, 2
 DETECT_ORB, DETECT_GRID = 0, 1
 TIMING_SLOTS = 64  # MO_TIMING_SLOTS of the library: event sets kept for Context.stage_times(back)
@@ -103,6 +118,11 @@ SIGNATURES = {
     "mo_dev_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mo_dev_match_pairs": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     "mo_dev_status": (_i, [_vp, _vp]),
+    "mo_stream_create": (_vp, [_vp, _vp, _vp]),
+    "mo_stream_destroy": (None, [_vp]),
+    "mo_stream_submit": (_i, [_vp, _vp, _i, _i, C.c_size_t]),
+    "mo_stream_collect": (_i, [_vp, _vp]),
+    "mo_stream_last_error": (C.c_char_p, [_vp]),
     "mo_comm_unique_id": (_i, [_vp]),
     "mo_comm_init": (_i, [_vp, _vp, _i, _i]),
     "mo_comm_destroy": (_i, [_vp]),
