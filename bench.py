@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the batch the CPU baseline processes (bounded sample)")
     ap.add_argument("--frames-cache", default="", help="file the generated frames of this rank are kept in (.npy; created when missing): "
                                                        "profiles/collect.sh generates once and profiles only the pipeline")
+    ap.add_argument("--no-check", action="store_true", help="timing-only ablation builds (tools/fast_ablate.sh) produce garbage on purpose: skip the output asserts")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs (other scene, next rows, H2D-inclusive, single-frame)")
     args = ap.parse_args()
 
@@ -251,6 +252,9 @@ def main():
             """after a leg's synchronisation: no capacity flag was raised by any call of the leg (a clamped overflow would otherwise
             pass unnoticed: the kernels never fault, they clamp and raise a bit) and the outputs are populated"""
             st = self.ctx.dev_status()
+            if args.no_check:
+                status[leg] = st
+                return
             assert st == 0, "leg %s: mo_dev_status = %d (capacity flag raised inside a timed region)" % (leg, st)
             status[leg] = st
             assert int(self.counts.min().item()) > 0, "leg %s: a frame without keypoints" % leg
@@ -713,24 +717,32 @@ def main():
             from vslam_amd.stream import FrameStream
             host_frames = pl.frames.cpu().numpy()
             legs = {}
-            for name, kw in (("track_orb", dict()), ("track_orb_views", dict(copy=False)), ("track_grid_views", dict(copy=False, detector=V.DETECT_GRID))):
+            for name, kw in (("track_orb_views", dict(copy=False)), ("track_orb_copies", dict()), ("track_orb_views_iterator", dict(copy=False)),
+                             ("track_grid_views", dict(copy=False, detector=V.DETECT_GRID))):
                 fs = FrameStream(K, width=W, height=H, chunk=64, n_features=NFEAT, cap=CAP, n_hyp=N_HYP, **kw)
                 try:
-                    n_seen = sum(1 for _ in fs.run(iter(host_frames[:130])))   # (warm-up: plan, buffers, clocks)
+                    src = (lambda a: iter(a)) if name.endswith("_iterator") else (lambda a: a)
+                    n_seen = sum(1 for _ in fs.run(src(host_frames[:130])))   # (warm-up: plan, buffers, clocks)
                     reps = max(2, args.steps // 5)
                     t1 = time.perf_counter()
-                    n_seen = 0
+                    n_seen, n_in = 0, 0
                     for _ in range(reps):
-                        for r in fs.run(iter(host_frames)):
+                        for r in fs.run(src(host_frames)):
                             n_seen += 1
+                            p = r.pair                      # (the consumer reads every frame's pose + kept matches and its feature arrays)
+                            if p is not None:
+                                n_in += p["n_inliers"]
+                            n_in += len(r.keypoints) + len(r.descriptors)
                     el = time.perf_counter() - t1
                 finally:
                     fs.close()
                 legs[name] = {"value": round(n_seen / el, 1), "unit": "frames/s", "frames": n_seen, "ms_per_64_frame_chunk": round(el / n_seen * 64e3, 3)}
-            legs["note"] = ("FrameStream over the bench's own frames as pageable host arrays, chunk 64: staging into pinned memory (host threads), "
-                            "H2D, one mo_dev_frontend_batch per chunk in tracking mode (ratio test, 2 filters, 8-pt RANSAC %d hyp at 1 px), results "
-                            "D2H, one Python FrameResult per frame; *_views: result arrays are views of the pinned buffer instead of copies; "
-                            "track_grid: the detector Tracker uses by default (distribute_keypoints)" % N_HYP)
+            legs["note"] = ("FrameStream over the bench's own 256 frames as a pageable host frame stack (N, H, W), chunk 64: staging into pinned memory "
+                            "(host threads), H2D on a copy stream, one mo_dev_frontend_batch per chunk in tracking mode (ratio test, 2 filters, 8-pt "
+                            "RANSAC %d hyp at 1 px), results D2H, one Python FrameResult per frame whose pose, kept matches, keypoints and "
+                            "descriptors the loop reads; *_views: result arrays are views of the pinned buffer, *_copies: the caller's own copies; "
+                            "*_iterator: the frames arrive one by one from a Python iterator (gathered into chunks frame by frame); track_grid: "
+                            "the detector Tracker uses by default (distribute_keypoints)" % N_HYP)
             out["streaming"] = legs
         out["dev_status"] = dict(status, note="mo_dev_status after every leg's synchronisation: 0 = no capacity flag raised (asserted)")
         if not args.no_cpu_baseline and world == 1:

@@ -296,12 +296,12 @@ int mo_dev_match_pairs(mo_ctx*, const uint8_t* d_desc, const int32_t* d_counts, 
  * A caller that can look a few frames ahead gets the batched mode's rate from host frames: mo_stream cuts the sequence into chunks, runs
  * every chunk as ONE mo_dev_frontend_batch call on chunk + 1 frames (the previous chunk's last frame is staged again in front, so every
  * consecutive pair of the sequence is matched exactly once) and overlaps the upload of chunk i + 1 and the caller's handling of chunk
- * i - 1 with the compute of chunk i (two lanes of pinned / device buffers, a copy stream beside the context's stream).  The sampling
+ * i - 1 with the compute of chunk i (three lanes of pinned / device buffers, an upload and a download stream beside the context's stream).  The sampling
  * stream of a pair is keyed by its global index: poses equal those of a per-frame loop that passes mo_pair_params.pair_index.
  *   mo_stream_submit   n <= chunk host frames (u8, rows of `stride` bytes, frames `frame_stride` bytes apart; 0 = dense): staged by a few
- *                      host threads, uploaded and enqueued; returns without waiting.  At most two chunks may be in flight.
+ *                      host threads, uploaded and enqueued; returns without waiting.  At most three chunks may be in flight.
  *   mo_stream_collect  waits for the OLDEST chunk in flight and describes its results: pointers into the lane's pinned host buffer,
- *                      valid until the second submit after this collect.  MO_ERR_CAPACITY when a capacity flag was raised inside the
+ *                      valid until the third submit after the chunk's own.  MO_ERR_CAPACITY when a capacity flag was raised inside the
  *                      chunk (r->flags, bits as in mo_dev_status; the results are still described). */
 typedef struct {
     int32_t w, h, ch;          /* frames: u8, ch = 1 (gray) or 3 (BGR, converted on the device) */

@@ -251,6 +251,17 @@ def test_frame_stream_equals_the_per_frame_loop(chunk, detector):
     finally:
         fs.close()
     assert [g.index for g in got] == list(range(nfr)) and got[0].pair is None
+    # (copy=True, the default: the results outlive the stream.  Views of a copy=False stream are refused once their buffer is gone)
+    fv = FrameStream(K, chunk=chunk, n_features=2000, cap=2048, detector=V.DETECT_GRID if grid else V.DETECT_ORB, n_hyp=64, copy=False)
+    try:
+        stale = list(fv.run(frames[:3 * chunk + 1] if 3 * chunk + 1 <= nfr else np.concatenate([frames, frames])[:3 * chunk + 1]))
+        assert len(stale[-1].keypoints) > 300              # the last chunk's buffer is still there
+        with pytest.raises(RuntimeError):
+            stale[0].keypoints                              # chunk 1's lane was reused by chunk 4
+    finally:
+        fv.close()
+    with pytest.raises(RuntimeError):
+        stale[-1].descriptors
     ctx = V.Context(device=0, max_w=640, max_h=480, max_batch=1)
     prm = V.orb_params(nfeatures=2000)
     last = None

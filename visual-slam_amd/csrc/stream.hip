@@ -9,12 +9,16 @@
 // sequence is matched exactly once - and the sampling stream of a pair is keyed by its GLOBAL index (mo_batch_io.pair_index_base): poses
 // equal those of a per-frame loop that counts its pairs (mo_pair_params.pair_index), bit for bit.
 //
-// Two lanes (pinned host input, device frames, device results, pinned host results, events) alternate:
+// Three lanes (pinned host input, device frames, device results, pinned host results, events) take turns:
 //   submit(k):  host threads copy the caller's frames into the lane's pinned input; copy stream: H2D; compute stream (the context's):
-//               wait for the copy, (BGR -> gray), mo_dev_frontend_batch, results -> the lane's pinned output, flag words with them
+//               wait for the copy, (BGR -> gray), mo_dev_frontend_batch, flag words into the result slab; download stream: results -> the
+//               lane's pinned output (the compute stream is free for the next chunk while they travel)
 //   collect():  waits for the oldest submitted chunk's results only (an event, not the stream: the next chunk keeps running)
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -24,13 +28,60 @@ namespace {
 
 inline size_t al(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
+// a few persistent host threads for the staging copies (spawning seven threads per chunk cost 0.2 ms of a 1.1 ms chunk period)
+class CopyPool {
+public:
+    explicit CopyPool(int n) {
+        for (int t = 0; t < n; t++) th_.emplace_back([this, t] { loop(t); });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; gen_++; }
+        cv_.notify_all();
+        for (std::thread& t : th_) t.join();
+    }
+    int size() const { return (int)th_.size() + 1; }
+    // runs work(t) for t = 0 .. size() - 1 (the caller takes the last index itself) and returns when all are done
+    void run(const std::function<void(int)>& work) {
+        { std::lock_guard<std::mutex> g(m_); work_ = &work; left_ = (int)th_.size(); gen_++; }
+        cv_.notify_all();
+        work((int)th_.size());
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return left_ == 0; });
+        work_ = nullptr;
+    }
+private:
+    void loop(int t) {
+        unsigned long seen = 0;
+        for (;;) {
+            const std::function<void(int)>* w;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                w = work_;
+            }
+            (*w)(t);
+            { std::lock_guard<std::mutex> g(m_); left_--; }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)>* work_ = nullptr;
+    int left_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+};
+
 struct Lane {
     uint8_t* h_in = nullptr;    // pinned [chunk + 1][h][w][ch]
     uint8_t* d_in = nullptr;    // device, the same
     uint8_t* d_gray = nullptr;  // device [chunk + 1][h][w] (ch == 3 only; ch == 1: d_in is the gray batch)
     uint8_t* d_out = nullptr;   // device results, one slab (offsets in mo_stream)
     uint8_t* h_out = nullptr;   // pinned, the same layout
-    hipEvent_t copied = nullptr, done = nullptr;
+    hipEvent_t copied = nullptr, computed = nullptr, done = nullptr;
     int n_frames = 0;           // frames of the chunk in flight (without the halo); 0 = lane free
     int halo = 0;               // 1: frame 0 of the batch is the previous chunk's last frame
     uint64_t first_frame = 0;   // global index of the chunk's first own frame
@@ -38,18 +89,21 @@ struct Lane {
 
 }  // namespace
 
+#define MO_STREAM_LANES 3   // chunks in flight: one being staged / uploaded, one computing, one downloading / being read by the caller
+
 struct mo_stream {
     mo_ctx* c = nullptr;
     mo_orb_params orb{};
     mo_stream_params p{};
-    hipStream_t copy_s = nullptr;
-    Lane lane[2];
+    hipStream_t copy_s = nullptr, down_s = nullptr;  // uploads / downloads, beside the context's stream (compute)
+    Lane lane[MO_STREAM_LANES];
     size_t frame_in = 0, frame_px = 0;
     // result slab offsets (rows: B = chunk + 1 frames, P = chunk pairs)
     size_t o_flags = 0, o_counts = 0, o_kps = 0, o_desc = 0, o_midx = 0, o_mdist = 0, o_mpass = 0, o_sel = 0, o_seld = 0, o_seln = 0, o_pose = 0,
            o_mask = 0, o_npts = 0, o_pts = 0, out_bytes = 0;
     uint64_t submitted = 0, collected = 0;  // chunks
     uint64_t frames_in = 0;                 // frames submitted so far
+    CopyPool* pool = nullptr;
     std::string err;
 };
 
@@ -60,6 +114,7 @@ extern "C" void mo_stream_destroy(mo_stream* s) {
     if (!s) return;
     if (s->c) { hipSetDevice(s->c->device); hipStreamSynchronize(s->c->stream); }
     if (s->copy_s) { hipStreamSynchronize(s->copy_s); hipStreamDestroy(s->copy_s); }
+    if (s->down_s) { hipStreamSynchronize(s->down_s); hipStreamDestroy(s->down_s); }
     for (Lane& l : s->lane) {
         if (l.h_in) hipHostFree(l.h_in);
         if (l.h_out) hipHostFree(l.h_out);
@@ -68,7 +123,9 @@ extern "C" void mo_stream_destroy(mo_stream* s) {
         if (l.d_out) hipFree(l.d_out);
         if (l.copied) hipEventDestroy(l.copied);
         if (l.done) hipEventDestroy(l.done);
+        if (l.computed) hipEventDestroy(l.computed);
     }
+    delete s->pool;
     delete s;
 }
 
@@ -96,7 +153,7 @@ extern "C" mo_stream* mo_stream_create(mo_ctx* c, const mo_orb_params* orb, cons
     s->o_midx = take(P * cap * 8); s->o_mdist = take(P * cap * 8); s->o_mpass = take(P * cap);
     s->o_pts = take(p->want_points ? P * cap * 3 * sizeof(float) : 16);
     s->out_bytes = off;
-    bool ok = hipStreamCreateWithFlags(&s->copy_s, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&s->copy_s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&s->down_s, hipStreamNonBlocking) == hipSuccess;
     for (Lane& l : s->lane) {
         ok = ok && hipHostMalloc((void**)&l.h_in, B * s->frame_in, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&l.h_out, s->out_bytes, hipHostMallocDefault) == hipSuccess;
@@ -105,17 +162,20 @@ extern "C" mo_stream* mo_stream_create(mo_ctx* c, const mo_orb_params* orb, cons
         ok = ok && hipMalloc((void**)&l.d_out, s->out_bytes) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&l.copied, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&l.done, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&l.computed, hipEventDisableTiming) == hipSuccess;
         if (ok) hipMemset(l.d_out, 0, s->out_bytes);
     }
     if (!ok) { mo_fail(c, MO_ERR_HIP, "mo_stream_create: allocation failed"); mo_stream_destroy(s); return nullptr; }
+    const size_t chunk_mb = (size_t)p->chunk * s->frame_in >> 20;
+    s->pool = new CopyPool((int)std::min<size_t>(7, chunk_mb / 2));  // (+ the calling thread; small chunks are copied by the caller alone)
     return s;
 }
 
-// the caller's frames -> the lane's pinned input, rows of `stride` bytes, on a few host threads (a 64-frame chunk is 19.7 MB: one core's
-// memcpy would cap the stream near 30 k frames/s)
-static void stage_frames(uint8_t* dst, const uint8_t* src, int n, size_t frame_in, size_t row, int h, size_t stride, size_t frame_stride) {
-    const int nthreads = (int)std::min<size_t>(8, std::max<size_t>(1, (size_t)n * frame_in >> 20));
-    auto work = [=](int t) {
+// the caller's frames -> the lane's pinned input, rows of `stride` bytes, on the pool's host threads (a 64-frame chunk is 19.7 MB: one
+// core's memcpy would cap the stream near 30 k frames/s)
+static void stage_frames(CopyPool* pool, uint8_t* dst, const uint8_t* src, int n, size_t frame_in, size_t row, int h, size_t stride, size_t frame_stride) {
+    const int nthreads = pool->size();
+    std::function<void(int)> work = [=](int t) {
         for (int f = t; f < n; f += nthreads) {
             const uint8_t* sf = src + (size_t)f * frame_stride;
             uint8_t* df = dst + (size_t)f * frame_in;
@@ -123,11 +183,7 @@ static void stage_frames(uint8_t* dst, const uint8_t* src, int n, size_t frame_i
             else for (int y = 0; y < h; y++) std::memcpy(df + (size_t)y * row, sf + (size_t)y * stride, row);
         }
     };
-    if (nthreads == 1) { work(0); return; }
-    std::vector<std::thread> th;
-    for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
-    work(0);
-    for (std::thread& t : th) t.join();
+    pool->run(work);
 }
 
 extern "C" int mo_stream_submit(mo_stream* s, const uint8_t* frames, int n, int stride, size_t frame_stride) {
@@ -137,18 +193,18 @@ extern "C" int mo_stream_submit(mo_stream* s, const uint8_t* frames, int n, int 
     if (stride == 0) stride = (int)row;
     if (frame_stride == 0) frame_stride = (size_t)stride * s->p.h;
     if ((size_t)stride < row) return sfail(s, MO_ERR_ARG, "mo_stream_submit: stride smaller than a row");
-    if (s->submitted - s->collected >= 2) return sfail(s, MO_ERR_CAPACITY, "mo_stream_submit: both lanes hold uncollected chunks (call mo_stream_collect)");
+    if (s->submitted - s->collected >= MO_STREAM_LANES) return sfail(s, MO_ERR_CAPACITY, "mo_stream_submit: every lane holds an uncollected chunk (call mo_stream_collect)");
     mo_ctx* c = s->c;
     SCHK(s, hipSetDevice(c->device));
-    Lane& l = s->lane[s->submitted & 1];
-    const Lane& prev = s->lane[(s->submitted + 1) & 1];
+    Lane& l = s->lane[s->submitted % MO_STREAM_LANES];
+    const Lane& prev = s->lane[(s->submitted + MO_STREAM_LANES - 1) % MO_STREAM_LANES];
     const int halo = s->frames_in > 0 ? 1 : 0;
     // (the lane's buffers are free: its previous chunk was collected, i.e. its `done` event has been waited for)
     if (halo) {  // the previous chunk's last frame again, in front
         const Lane& src = s->submitted > 0 ? prev : l;
         std::memcpy(l.h_in, src.h_in + (size_t)(src.halo + src.n_frames - 1) * s->frame_in, s->frame_in);
     }
-    stage_frames(l.h_in + (size_t)halo * s->frame_in, frames, n, s->frame_in, row, s->p.h, (size_t)stride, frame_stride);
+    stage_frames(s->pool, l.h_in + (size_t)halo * s->frame_in, frames, n, s->frame_in, row, s->p.h, (size_t)stride, frame_stride);
     l.n_frames = n; l.halo = halo; l.first_frame = s->frames_in;
     const int nb = n + halo;
     SCHK(s, hipMemcpyAsync(l.d_in, l.h_in, (size_t)nb * s->frame_in, hipMemcpyHostToDevice, s->copy_s));
@@ -186,9 +242,14 @@ extern "C" int mo_stream_submit(mo_stream* s, const uint8_t* frames, int n, int 
     // results -> pinned host: the flag words of this call travel with them (and are cleared for the next chunk)
     SCHK(s, hipMemcpyAsync(o + s->o_flags, c->d_flags, 16, hipMemcpyDeviceToDevice, c->stream));
     SCHK(s, hipMemsetAsync(c->d_flags, 0, 16, c->stream));
+    // ... on a THIRD stream: the compute stream goes straight on to the next chunk, and the upload stream is never held up behind a
+    // download that waits for a compute (one copy stream for both directions serialised upload (k + 1) behind compute (k): 38 k frames/s
+    // at any chunk size)
     const size_t upto = s->p.mode == MO_MODE_TRACK && !s->p.want_matches ? s->o_midx : s->p.want_points ? s->out_bytes : s->o_pts;
-    SCHK(s, hipMemcpyAsync(l.h_out, o, upto, hipMemcpyDeviceToHost, c->stream));
-    SCHK(s, hipEventRecord(l.done, c->stream));
+    SCHK(s, hipEventRecord(l.computed, c->stream));
+    SCHK(s, hipStreamWaitEvent(s->down_s, l.computed, 0));
+    SCHK(s, hipMemcpyAsync(l.h_out, o, upto, hipMemcpyDeviceToHost, s->down_s));
+    SCHK(s, hipEventRecord(l.done, s->down_s));
     s->submitted++;
     s->frames_in += n;
     return MO_OK;
@@ -198,7 +259,7 @@ extern "C" int mo_stream_collect(mo_stream* s, mo_stream_result* r) {
     if (!s || !r) return MO_ERR_ARG;
     if (s->collected >= s->submitted) return sfail(s, MO_ERR_ARG, "mo_stream_collect: nothing submitted");
     SCHK(s, hipSetDevice(s->c->device));
-    Lane& l = s->lane[s->collected & 1];
+    Lane& l = s->lane[s->collected % MO_STREAM_LANES];
     SCHK(s, hipEventSynchronize(l.done));
     const uint8_t* h = l.h_out;
     const size_t cap = (size_t)s->p.cap;

@@ -193,14 +193,21 @@ def run_batched(args, cfg, K, D, orb, mt, initializer, source, limit, skip, t0):
                 continue
             seen += 1
             yield geom.undistort_image(frame, K, D) if np.any(D) else frame
-    frames = selected()
+    stack = None
+    if args.frames and not os.path.isdir(args.frames) and not np.any(D) and not skip:   # a frame stack on disk: handed over as slices
+        data = np.load(args.frames)   # (read into memory: a memory-mapped stack would page-fault inside the staging copies)
+        arr = data[sorted(data.files)[0]] if hasattr(data, "files") else data
+        stack = np.ascontiguousarray(arr[:limit] if limit < 10 ** 9 else arr, dtype=np.uint8)
+    frames = iter(stack) if stack is not None else selected()
     first = next(frames, None)
     if first is None:
         return "NOT_INITIALIZED", [], 0
     h, w = first.shape[:2]
     prm = V.orb_params(nfeatures=orb["n_features"], scale_factor=orb["scale_factor"], nlevels=orb["n_levels"], fast_threshold=orb["min_threshold"])
     fs = FrameStream(K, width=w, height=h, channels=3 if first.ndim == 3 else 1, chunk=args.batch, prm=prm,
-                     detector=V.DETECT_GRID if args.grid else V.DETECT_ORB, ratio=mt["ratio_threshold"], disp_frac=0.02, thr_px=1.0)
+                     detector=V.DETECT_GRID if args.grid else V.DETECT_ORB, ratio=mt["ratio_threshold"], disp_frac=0.02, thr_px=1.0, copy=False)
+    # (copy=False: the results are views of the stream's pinned buffers, valid while iterating; what this loop keeps - the keypoints and
+    #  descriptors the initialiser holds on to, the poses - is copied explicitly.  A tracking frame only reads its pose: 12 doubles.)
     matcher = DescriptorMatcher(mt["matcher_type"], ratio_threshold=mt["ratio_threshold"])
     kept = {0: first}   # (frames the initialiser may still want: the first one, and the one being initialised against)
 
@@ -210,30 +217,39 @@ def run_batched(args, cfg, K, D, orb, mt, initializer, source, limit, skip, t0):
             if state[0] == "NOT_INITIALIZED":
                 kept[i] = f
             yield f
+    feed = stack if stack is not None else chain()
+    frame_at = (lambda i: stack[i]) if stack is not None else (lambda i: kept.get(i, first))
     state, poses, n_map, n_seen = ["NOT_INITIALIZED"], [], 0, 0
     try:
-        for r in fs.run(chain()):
+        t_steady, n_steady = None, 0
+        for r in fs.run(feed):
             n_seen += 1
-            kps, desc = KeyPointSeq(r.keypoints), r.descriptors
+            if n_seen == 3 * args.batch + 1:     # (steady state: context, plan and the three lanes warmed up by the first chunks)
+                t_steady, n_steady = time.perf_counter(), n_seen - 1
             if state[0] == "NOT_INITIALIZED":
+                kps, desc = KeyPointSeq(r.keypoints.copy()), r.descriptors.copy()
                 if initializer.first_frame_keypoints is None:
-                    initializer.set_first_frame(kps, desc, kept[r.index])
+                    initializer.set_first_frame(kps, desc, frame_at(r.index))
                 else:
-                    ok, R, t, pts, matches = initializer.initialize(kps, desc, matcher, kept.get(r.index, first))
+                    ok, R, t, pts, matches = initializer.initialize(kps, desc, matcher, frame_at(r.index))
                     if ok:
                         state[0], n_map = "TRACKING", len(pts)
                         kept.clear()
                         poses.append((R, t))
                         print("frame %d: initialised, %d map points, t = %s" % (r.index, n_map, np.round(t.ravel(), 3)))
-            elif r.pair is not None and r.pair["ok"]:
-                poses.append((r.pair["R"], r.pair["t"]))
-                if r.index % 5 == 0:
-                    print("frame %d: %d pose inliers, t = %s" % (r.index, int(r.pair["inlier"].sum()), np.round(r.pair["t"].ravel(), 3)))
+            else:
+                p = r.pair
+                if p is not None and p.ok:
+                    poses.append((p.R.copy(), p.t.copy()))
+                    if r.index % 100 == 0:
+                        print("frame %d: %d pose inliers, t = %s" % (r.index, int(p.inlier.sum()), np.round(p.t.ravel(), 3)))
     finally:
         fs.close()
-    dt = time.perf_counter() - t0
-    print("%d frames in %.2f s (%.1f frames/s through FrameStream, chunks of %d), state %s, %d poses"
-          % (n_seen, dt, n_seen / max(dt, 1e-9), args.batch, state[0], len(poses)))
+    t_end = time.perf_counter()
+    dt = t_end - t0
+    steady = "" if t_steady is None else "; %.0f frames/s from the fourth chunk on" % ((n_seen - n_steady) / max(t_end - t_steady, 1e-9))
+    print("%d frames in %.2f s (%.1f frames/s through FrameStream incl. start-up, chunks of %d%s), state %s, %d poses"
+          % (n_seen, dt, n_seen / max(dt, 1e-9), args.batch, steady, state[0], len(poses)))
     return state[0], poses, n_map
 
 

@@ -21,11 +21,135 @@ from . import (DETECT_GRID, DETECT_ORB, KP_DTYPE, MODE_INIT, MODE_TRACK, MO_ERR_
                StreamResult, orb_params)
 
 
-class FrameResult:
-    __slots__ = ("index", "keypoints", "descriptors", "pair")
+LANES = 3   # MO_STREAM_LANES of the library: chunks in flight
 
-    def __init__(self, index, keypoints, descriptors, pair):
-        self.index, self.keypoints, self.descriptors, self.pair = index, keypoints, descriptors, pair
+
+class _Chunk:
+    """the arrays of one collected chunk (views of the lane's pinned result buffer) and what is needed to cut a frame's part out of them"""
+    __slots__ = ("counts", "kps", "desc", "pose", "npts", "mask", "sel", "seld", "seln", "midx", "mdist", "mpass", "pts", "off", "prev_count",
+                 "first_frame", "first_pair", "cap", "track", "copy", "stream", "serial", "ok")
+
+    def check(self):
+        """copy=False: the arrays are views of a lane's pinned buffer, which the second submit after this chunk's collect overwrites
+        (and close() frees): reading them later fails loudly instead of returning another chunk's data"""
+        if self.copy:
+            return
+        st = self.stream
+        if st is None or st.h_stream is None or st._submitted - self.serial >= LANES:
+            raise RuntimeError("FrameResult of a FrameStream(copy=False) read after its pinned buffer was reused or the stream closed: "
+                               "read the arrays while iterating, or create the stream with copy=True")
+
+
+class FrameResult:
+    """One frame of the sequence.  .index; .keypoints (KP_DTYPE records), .descriptors (n, 32) uint8; .pair: None for frame 0, else the
+    PairResult of the pair step against frame index - 1.  The arrays are cut out of the chunk when they are first asked for (with
+    copy=True, the default, the chunk's arrays are the caller's own copies; with copy=False views of the pinned result buffer)."""
+    __slots__ = ("index", "_c", "_f", "_kp", "_de", "_pr")
+
+    def __init__(self, index, chunk, f):
+        self.index, self._c, self._f = index, chunk, f
+        self._kp = self._de = self._pr = None
+
+    def _own(self, x):
+        return x   # (copy=True: the chunk's arrays already are the caller's own copies, made in bulk at collect)
+
+    @property
+    def keypoints(self):
+        if self._kp is None:
+            self._c.check()
+            self._kp = self._own(self._c.kps[self._f, :int(self._c.counts[self._f])])
+        return self._kp
+
+    @property
+    def descriptors(self):
+        if self._de is None:
+            self._c.check()
+            self._de = self._own(self._c.desc[self._f, :int(self._c.counts[self._f])])
+        return self._de
+
+    @property
+    def pair(self):
+        c = self._c
+        j = self._f - c.off                            # pair row whose TRAIN frame is this frame
+        if j < 0:
+            return None
+        if self._pr is None:
+            c.check()
+            self._pr = PairResult(c, j, self._f)
+        return self._pr
+
+
+class PairResult:
+    """The pair step of one frame against its predecessor; fields are cut out of the chunk when asked for (attribute or ["key"] access).
+    MODE_TRACK: ok (>= 8 kept matches and a model, tracker.py:234), R (3, 3), t (3, 1), n_inliers, pair_index, sel (m, 2) [queryIdx, trainIdx]
+    in the reference's order, sel_dist (m,), inlier (m,) bool.  MODE_INIT: ok, R, t, n_inliers, pair_index, idx / dist (n_prev, 2), keep,
+    pose_mask (n_prev,) bool[, X (n_prev, 3)]."""
+    __slots__ = ("_c", "_j", "_f", "_inl")
+
+    def __init__(self, chunk, j, f):
+        self._c, self._j, self._f, self._inl = chunk, j, f, None
+
+    def __getitem__(self, key):
+        try:
+            return getattr(self, key)
+        except AttributeError:
+            raise KeyError(key)
+
+    def __contains__(self, key):
+        return hasattr(self, key)
+
+    @property
+    def _nq(self):
+        c = self._c
+        return min(int(c.prev_count) if (self._j == 0 and c.off == 0) else int(c.counts[self._f - 1]), c.cap)
+
+    ok = property(lambda self: bool(self._c.ok[self._j]))
+    R = property(lambda self: self._c.pose[self._j, :9].reshape(3, 3))
+    t = property(lambda self: self._c.pose[self._j, 9:].reshape(3, 1))
+    n_inliers = property(lambda self: int(self._c.npts[self._j]) if self._c.ok[self._j] else 0)
+    pair_index = property(lambda self: self._c.first_pair + self._j)
+
+    @property
+    def sel(self):
+        c = self._c
+        if not c.track:
+            raise AttributeError("sel")
+        return c.sel[self._j, :int(c.seln[self._j])]
+
+    @property
+    def sel_dist(self):
+        c = self._c
+        if not c.track:
+            raise AttributeError("sel_dist")
+        return c.seld[self._j, :int(c.seln[self._j])]
+
+    @property
+    def inlier(self):
+        c = self._c
+        if not c.track:
+            raise AttributeError("inlier")
+        if self._inl is None:
+            s = self.sel
+            self._inl = (c.mask[self._j][s[:, 0]] != 0) if c.ok[self._j] else np.zeros(len(s), bool)
+        return self._inl
+
+    @property
+    def pose_mask(self):
+        c = self._c
+        if c.track:
+            raise AttributeError("pose_mask")
+        return c.mask[self._j, :self._nq].view(bool)
+
+    def _knn(self, name):
+        a = getattr(self._c, name)
+        if a is None:
+            raise AttributeError(name)
+        return a[self._j, :self._nq]
+
+    idx = property(lambda self: self._knn("midx"))
+    dist = property(lambda self: self._knn("mdist"))
+    keep = property(lambda self: self._knn("mpass").view(bool))
+    X = property(lambda self: self._knn("pts"))
 
 
 def _view(ptr, shape, dtype):
@@ -42,7 +166,7 @@ class FrameStream:
         """copy=True: every yielded array is the caller's own (a copy out of the pinned result buffer); copy=False: views that stay valid
         until two more chunks have been submitted (the benchmark's rate without the per-frame copies)"""
         self.prm = prm if prm is not None else orb_params(nfeatures=n_features)
-        self.cap = int(cap or ((self.prm.nfeatures + 63) // 64 * 64 + 48))
+        self.cap = int(cap or ((self.prm.nfeatures + 48 + 63) // 64 * 64))   # (retainBest keeps ties: a few rows beyond nfeatures)
         self.chunk, self.w, self.h, self.ch, self.mode, self.copy = int(chunk), int(width), int(height), int(channels), int(mode), bool(copy)
         self.ctx = Context(device=device, max_w=self.w, max_h=self.h, max_batch=self.chunk + 1)
         sp = StreamParams()
@@ -59,7 +183,7 @@ class FrameStream:
         if not self.h_stream:
             raise NativeError(-1, self.ctx.lib.mo_last_error(self.ctx.h).decode())
         self._in_flight = 0
-        self._prev = None  # (keypoint records, count) of the frame in front of the next chunk
+        self._submitted = 0
 
     def close(self):
         if getattr(self, "h_stream", None):
@@ -83,6 +207,7 @@ class FrameStream:
         if rc != MO_OK:
             raise NativeError(rc, self.ctx.lib.mo_stream_last_error(self.h_stream).decode())
         self._in_flight += 1
+        self._submitted += 1
 
     def collect(self):
         """results of the oldest chunk in flight -> list of FrameResult"""
@@ -94,68 +219,69 @@ class FrameStream:
         if rc == MO_ERR_CAPACITY:
             raise NativeError(rc, "capacity flag %d raised inside a streamed chunk (cap = %d rows per frame)" % (r.flags, r.cap))
         nf, npair, cap = r.n_frames, r.n_pairs, r.cap
-        counts = np.minimum(_view(r.counts, (nf,), np.int32), cap)
-        kps = _view(r.kps, (nf, cap), KP_DTYPE)
-        desc = _view(r.desc, (nf, cap, 32), np.uint8)
-        pose = _view(r.pose, (npair, 12), np.float64)
-        npts = _view(r.n_points, (npair,), np.int32)
-        mask = _view(r.pose_mask, (npair, cap), np.uint8)
-        track = self.mode == MODE_TRACK
-        if track:
-            sel = _view(r.sel_idx, (npair, cap, 2), np.int32)
-            seld = _view(r.sel_dist, (npair, cap), np.int32)
-            seln = np.minimum(_view(r.sel_n, (npair,), np.int32), cap)
+        c = _Chunk()
+        c.cap, c.copy, c.track = cap, self.copy, self.mode == MODE_TRACK
+        c.counts = np.minimum(_view(r.counts, (nf,), np.int32), cap)
+        c.kps = _view(r.kps, (nf, cap), KP_DTYPE)
+        c.desc = _view(r.desc, (nf, cap, 32), np.uint8)
+        c.pose = _view(r.pose, (npair, 12), np.float64)
+        c.npts = _view(r.n_points, (npair,), np.int32)
+        c.mask = _view(r.pose_mask, (npair, cap), np.uint8)
+        c.sel = c.seld = c.seln = c.midx = c.mdist = c.mpass = c.pts = None
+        if c.track:
+            c.sel = _view(r.sel_idx, (npair, cap, 2), np.int32)
+            c.seld = _view(r.sel_dist, (npair, cap), np.int32)
+            c.seln = np.minimum(_view(r.sel_n, (npair,), np.int32), cap)
         if r.match_idx:
-            midx = _view(r.match_idx, (npair, cap, 2), np.int32); mdist = _view(r.match_dist, (npair, cap, 2), np.int32)
-            mpass = _view(r.match_pass, (npair, cap), np.uint8)
-        pts = _view(r.points, (npair, cap, 3), np.float32) if r.points else None
-        own = (lambda x: x.copy()) if self.copy else (lambda x: x)
-        off = 1 if r.first_pair == r.first_frame else 0   # first chunk: frame row 0 has no pair in front of it
-        out = []
-        for f in range(nf):
-            n = int(counts[f])
-            pr = None
-            j = f - off                                    # pair row whose TRAIN frame is this frame
-            if j >= 0:
-                nq = int(r.prev_count) if (j == 0 and off == 0) else int(counts[f - 1])
-                nq = min(nq, cap)
-                P = pose[j]
-                pr = dict(R=P[:9].reshape(3, 3).copy(), t=P[9:].reshape(3, 1).copy(), n_inliers=int(npts[j]), pair_index=int(r.first_pair) + j)
-                if track:
-                    m = int(seln[j])
-                    s = sel[j, :m]
-                    ok = m >= 8 and bool(np.isfinite(P).all())      # tracker.py:234
-                    pr.update(sel=own(s), sel_dist=own(seld[j, :m]), inlier=(mask[j][s[:, 0]] != 0) if ok else np.zeros(m, bool), ok=ok)
-                    if not ok:
-                        pr["n_inliers"] = 0
-                else:
-                    pr.update(pose_mask=own(mask[j, :nq]).view(bool), ok=bool(np.isfinite(P).all()))
-                if r.match_idx:
-                    pr.update(idx=own(midx[j, :nq]), dist=own(mdist[j, :nq]), keep=own(mpass[j, :nq]).view(bool))
-                if pts is not None:
-                    pr["X"] = own(pts[j, :nq])
-            out.append(FrameResult(int(r.first_frame) + f, own(kps[f, :n]), own(desc[f, :n]), pr))
-        return out
+            c.midx = _view(r.match_idx, (npair, cap, 2), np.int32); c.mdist = _view(r.match_dist, (npair, cap, 2), np.int32)
+            c.mpass = _view(r.match_pass, (npair, cap), np.uint8)
+        if r.points:
+            c.pts = _view(r.points, (npair, cap, 3), np.float32)
+        if self.copy:   # the caller's own arrays: one bulk copy per array out of the pinned buffer (a FrameResult then slices these)
+            for name in ("kps", "desc", "pose", "npts", "mask", "sel", "seld", "seln", "midx", "mdist", "mpass", "pts"):
+                a = getattr(c, name)
+                if a is not None:
+                    setattr(c, name, a.copy())
+        finite = np.isfinite(c.pose).all(axis=1)
+        c.ok = (finite & (c.seln >= 8)) if c.track else finite   # tracker.py:234: fewer than 8 kept matches -> no pose
+        c.stream, c.serial = self, self._submitted - self._in_flight   # (index of this chunk + 1 among the submitted ones)
+        c.off = 1 if r.first_pair == r.first_frame else 0   # first chunk: frame row 0 has no pair in front of it
+        c.prev_count, c.first_frame, c.first_pair = int(r.prev_count), int(r.first_frame), int(r.first_pair)
+        first = c.first_frame
+        return [FrameResult(first + f, c, f) for f in range(nf)]
 
     # ---- iterator level --------------------------------------------------------------------------------------------------
     def run(self, frames):
-        """frames: iterable of uint8 arrays (H, W) or (H, W, 3) -> generator of FrameResult in frame order.  Two chunks are kept in
-        flight: while the GPU works on chunk i and uploads chunk i + 1, the caller consumes the results of chunk i - 1."""
+        """frames: an array (N, H, W[, 3]) uint8 - a frame stack: chunks are handed over as slices, no per-frame copy in Python - or any
+        iterable of (H, W[, 3]) uint8 arrays (gathered into chunks frame by frame) -> generator of FrameResult in frame order.  Up to
+        three chunks are in flight: while the GPU works on chunk i and uploads chunk i + 1, the caller consumes the results of chunk i - 1.
+        With copy=False a FrameResult's arrays must be read before two more chunks have been submitted (i.e. while iterating)."""
+        if isinstance(frames, np.ndarray) and frames.ndim == (4 if self.ch == 3 else 3):
+            for k in range(0, len(frames), self.chunk):
+                if self._in_flight == LANES:
+                    yield from self.collect()
+                self.submit(frames[k:k + self.chunk])
+                if self._in_flight == LANES:        # (the oldest chunk is read while the two younger ones upload / compute)
+                    yield from self.collect()
+            while self._in_flight:
+                yield from self.collect()
+            return
         shape = (self.chunk, self.h, self.w) + ((3,) if self.ch == 3 else ())
-        blocks = [np.empty(shape, np.uint8), np.empty(shape, np.uint8), np.empty(shape, np.uint8)]
-        k, fill = 0, 0
+        block = np.empty(shape, np.uint8)
+        fill = 0
         for fr in frames:
-            blocks[k % 3][fill] = fr
+            block[fill] = fr
             fill += 1
             if fill == self.chunk:
-                if self._in_flight == 2:
+                if self._in_flight == LANES:
                     yield from self.collect()
-                self.submit(blocks[k % 3])   # (staged into pinned memory inside the call: the block may be refilled at once)
-                k += 1
+                self.submit(block)   # (staged into pinned memory inside the call: the block is refilled at once)
                 fill = 0
+                if self._in_flight == LANES:
+                    yield from self.collect()
         if fill:
-            if self._in_flight == 2:
+            if self._in_flight == LANES:
                 yield from self.collect()
-            self.submit(blocks[k % 3][:fill])
+            self.submit(block[:fill])
         while self._in_flight:
             yield from self.collect()
