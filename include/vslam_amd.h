@@ -24,6 +24,13 @@
 extern "C" {
 #endif
 
+/* The structs below (mo_orb_params, mo_batch_io, mo_frame_ref, mo_pair_params, mo_pair_out, mo_stream_params, mo_stream_result) carry no size
+ * field: their layout belongs to the header a caller was compiled against.  mo_batch_io gets fields APPENDED per round, so a caller built
+ * against an older header hands in a shorter struct than the library reads: every caller must be recompiled with the header of the library
+ * it loads, and can check that at load time: mo_abi_version() == MO_ABI_VERSION. */
+#define MO_ABI_VERSION 4
+int mo_abi_version(void);
+
 #define MO_OK 0
 #define MO_ERR_ARG (-1)       /* bad argument */
 #define MO_ERR_HIP (-2)       /* HIP runtime error (see mo_last_error) */

@@ -25,13 +25,13 @@ extern "C" int mo_host_times(mo_ctx* c, double us[4]) {
     return MO_OK;
 }
 
-static bool grow_fin_slots(mo_ctx* c);
+static bool grow_fin_slots(mo_ctx* c, int levels);
 
 static int check_flags(mo_ctx* c) {
     int f[4] = {0, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(f, host_flags(c), sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (f[0] & 1) { c->tie_overflow = true; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
+    if (f[0] & 1) { c->tie_overflow = true; c->tie_levels = f[1]; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
     if (f[0] & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
     return MO_OK;
 }
@@ -43,8 +43,8 @@ extern "C" int mo_dev_status(mo_ctx* c, int32_t flags[4]) {
     HIPCHK(c, hipMemcpyAsync(f, c->d_flags, sizeof(f), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (flags) { flags[0] = f[0]; flags[1] = flags[2] = flags[3] = 0; }
-    if (f[0] & 1) grow_fin_slots(c);  // response ties overflowed a level's slot: the next call of the same shape rebuilds its plan with larger ones
+    if (flags) { flags[0] = f[0]; flags[1] = f[1]; flags[2] = flags[3] = 0; }
+    if (f[0] & 1) grow_fin_slots(c, f[1]);  // response ties overflowed a level's slot: the next call of the same shape rebuilds its plan with larger ones
     if (f[0] & 15) return mo_fail(c, MO_ERR_CAPACITY, "a capacity flag was raised by a mo_dev_* call (see mo_dev_status in vslam_amd.h)");
     return MO_OK;
 }
@@ -174,16 +174,18 @@ int mo_host_stage(mo_ctx* c, size_t bytes) {
 }
 static int host_stage(mo_ctx* c, size_t bytes) { return mo_host_stage(c, bytes); }
 
-// true when a level's final-keypoint slot can still grow (then the plan is invalidated so that the next call rebuilds it larger).
+// true when an overflowed level's final-keypoint slot can still grow (then the plan is invalidated so that the next call rebuilds it).
 // retainBest keeps EVERY element that ties with the quota boundary, so a level of a periodic synthetic pattern can keep all its
-// candidates; the slots are sized for 4 quota + 256 and grow eightfold per overflow up to the level's candidate capacity.
-static bool grow_fin_slots(mo_ctx* c) {
+// candidates; the slots are sized for 4 quota + 256 and the levels named in `levels` (bit L) grow eightfold, up to the level's
+// candidate capacity - the other levels, and other image sizes / parameter sets, keep their sizes.
+static bool grow_fin_slots(mo_ctx* c, int levels) {
     if (!c->plan_valid) return false;
-    bool room = false;
-    for (int L = 0; L < c->plan.nlevels; L++) room |= c->plan.lv[L].fin_cap < c->plan.lv[L].cand_cap;
-    if (!room || c->fin_slack >= (1 << 24)) return false;
-    c->fin_slack *= 8;
-    return true;
+    if (!levels) levels = (1 << c->plan.nlevels) - 1;  // (no level named: an older flag word; grow them all)
+    bool grown = false;
+    for (int L = 0; L < c->plan.nlevels; L++)
+        if (((levels >> L) & 1) && c->plan.lv[L].fin_cap < c->plan.lv[L].cand_cap && c->fin_slack[L] < (1 << 24)) { c->fin_slack[L] *= 8; grown = true; }
+    c->fin_slack_dirty = c->fin_slack_dirty || grown;
+    return grown;
 }
 
 static int detect_compute_once(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch,
@@ -194,9 +196,9 @@ extern "C" int mo_orb_detect_compute(mo_ctx* c, const mo_orb_params* p, const ui
     if (!c) return MO_ERR_ARG;
     if (!kps || !counts) return mo_fail(c, MO_ERR_ARG, "kps/counts is NULL");
     for (;;) {  // (at most 8 rounds: the slots reach the candidate capacity, where no overflow is possible)
-        c->tie_overflow = false;
+        c->tie_overflow = false; c->tie_levels = 0;
         const int rc = detect_compute_once(c, p, img, w, h, stride, ch, batch, kps, desc, cap, counts);
-        if (rc != MO_ERR_CAPACITY || !c->tie_overflow || !grow_fin_slots(c)) return rc;
+        if (rc != MO_ERR_CAPACITY || !c->tie_overflow || !grow_fin_slots(c, c->tie_levels)) return rc;
     }
 }
 
@@ -231,7 +233,7 @@ static int detect_compute_once(mo_ctx* c, const mo_orb_params* p, const uint8_t*
         clk.waited();
         std::memcpy(counts, hs + o_cnt, (size_t)batch * sizeof(int));  // MO_ERR_CAPACITY: counts already holds the sizes a retry needs
         const int fl = ((const int*)hs)[0];
-        if (fl & 1) { c->tie_overflow = true; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
+        if (fl & 1) { c->tie_overflow = true; c->tie_levels = ((const int*)hs)[1]; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
         if (fl & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
         for (int f = 0; f < batch; f++) {
             const int n = std::min(counts[f], cap);

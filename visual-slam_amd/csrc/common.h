@@ -77,8 +77,13 @@ struct mo_ctx {
 
     // plan (rebuilt when w, h or the ORB parameters change)
     bool plan_valid = false;
-    int fin_slack = 1, plan_fin_slack = 1;  // per-level final-keypoint slots = min(candidates, (4 quota + 256) x fin_slack): grown when response ties overflow them
+    // per-level final-keypoint slots = min(candidates, (4 quota + 256) x fin_slack[L]): a level whose response ties overflow its slot
+    // (flag bit 0; the kernel names the level in flag word 1) grows eightfold - that level only - and the plan is rebuilt; the factors
+    // start again at 1 whenever the image size or the ORB parameters change
+    int fin_slack[MO_MAX_LEVELS] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    bool fin_slack_dirty = false;           // a factor changed since the plan was built
     bool tie_overflow = false;              // the last host extraction raised flag bit 0
+    int tie_levels = 0;                     // ... on these levels (bit L)
     mo_orb_params plan_params{};
     Plan plan{};
     ResizeTab rtab[MO_MAX_LEVELS];

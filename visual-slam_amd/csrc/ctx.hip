@@ -25,6 +25,8 @@ static inline int cv_round_f(float v) { return (int)lrintf(v); }
 static inline int cv_round_d(double v) { return (int)lrint(v); }
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
+extern "C" int mo_abi_version(void) { return MO_ABI_VERSION; }
+
 extern "C" int mo_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -213,7 +215,10 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
     if (p->select_order != MO_ORDER_LIBSTDCXX && p->select_order != MO_ORDER_MSVC)
         return mo_fail(c, MO_ERR_ARG, "select_order must be MO_ORDER_LIBSTDCXX or MO_ORDER_MSVC");
 
-    bool same = c->plan_valid && params_equal(c->plan_params, *p) && c->plan.w == w && c->plan.h == h && c->plan_fin_slack == c->fin_slack;
+    const bool same_key = c->plan_valid && params_equal(c->plan_params, *p) && c->plan.w == w && c->plan.h == h;
+    const bool same = same_key && !c->fin_slack_dirty;
+    if (!same_key)   // another image size / parameter set: the grown slots were that one's
+        for (int L = 0; L < MO_MAX_LEVELS; L++) c->fin_slack[L] = 1;
     if (same && batch <= c->batch_alloc) return MO_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_plan_buffers(c);
@@ -296,7 +301,7 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         v.cand_cap = v.nstrips * v.strip_cap;
         cand_off += v.cand_cap;
         v.fin_off = fin_off;
-        v.fin_cap = (int)std::max<long long>(1, std::min<long long>(v.cand_cap, (4ll * v.quota + 256) * c->fin_slack));
+        v.fin_cap = (int)std::max<long long>(1, std::min<long long>(v.cand_cap, (4ll * v.quota + 256) * c->fin_slack[L]));
         fin_off += v.fin_cap;
         v.scr_off = scr_off;
         // u64 records B + u32 records A + u16 partner positions + u64 ballots, in u64 units
@@ -354,11 +359,13 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
     HIPCHK(c, hipMalloc((void**)&c->d_cand, B * P.cand_stride * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_strip_cnt, B * P.strips_per_frame * sizeof(int)));
     HIPCHK(c, hipMalloc((void**)&c->d_scratch, B * c->scratch_stride * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_fin, B * P.fin_stride * sizeof(FinalKp)));
+    if (hipMalloc((void**)&c->d_fin, B * P.fin_stride * sizeof(FinalKp)) != hipSuccess)
+        return mo_fail(c, MO_ERR_HIP, "hipMalloc of the final-keypoint slots failed: " + std::to_string(B * P.fin_stride * sizeof(FinalKp)) +
+                                          " bytes (" + std::to_string(batch) + " frames x " + std::to_string(P.fin_stride) + " slots; slots grow with response ties)");
     HIPCHK(c, hipMalloc((void**)&c->d_fin_cnt, B * MO_MAX_LEVELS * sizeof(int)));
     c->batch_alloc = batch;
     c->plan_params = *p;
     c->plan_valid = true;
-    c->plan_fin_slack = c->fin_slack;
+    c->fin_slack_dirty = false;
     return MO_OK;
 }

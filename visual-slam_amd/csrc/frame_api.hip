@@ -133,7 +133,7 @@ int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int 
     const int* ho = (const int*)(hs + o_out);
     const int fl = ho[0], total = ho[4];
     counts[0] = total;  // MO_ERR_CAPACITY: counts already holds the size a retry needs
-    if (fl & 1) { c->tie_overflow = true; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
+    if (fl & 1) { c->tie_overflow = true; c->tie_levels = ho[1]; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
     if (fl & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
     const int n = std::min(std::max(total, 0), cap);
     if (n > 0) {

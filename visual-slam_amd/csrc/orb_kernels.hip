@@ -965,7 +965,7 @@ __device__ __forceinline__ float harris_group(const uint32_t (&reg)[4], int x0, 
 template <int NT, class PA, class PB>
 __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv, const uint8_t* img, PA A, PB B, int N1,
                                               uint16_t* rpos, unsigned long long* bl, FinalKp* fin, int* fin_cnt_out,
-                                              int* flags, replay::WgScratch<NT>* ws, uint32_t (*s_hw)[27] /* [NT / HG] group-private windows */) {
+                                              int* flags, replay::WgScratch<NT>* ws, uint32_t (*s_hw)[27] /* [NT / HG] group-private windows */, int level) {
     const int tid = threadIdx.x;
     constexpr int HG_GROUPS = NT / HG;
     if ((lv.pitch & 3) == 0 && (((size_t)img) & 3) == 0) {  // block-uniform; a keypoint sits >= edge_threshold >= 4 columns inside its row
@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void select_harris(const Plan& P, const LevelInfo& lv
     __syncthreads();
     int N2 = replay::wg_retain_best<NT, uint64_t>(B, N1, lv.quota, P.select_order, rpos, bl, tid, ws);
     if (N2 > lv.fin_cap) {
-        if (tid == 0) atomicOr(&flags[0], 1);
+        if (tid == 0) { atomicOr(&flags[0], 1); atomicOr(&flags[1], 1 << level); }  // (word 1 names the level: only its slot grows)
         N2 = lv.fin_cap;
     }
     for (int i = tid; i < N2; i += NT) {
@@ -1094,10 +1094,10 @@ __global__ __launch_bounds__(NT) void k_select(Plan P, const uint8_t* __restrict
     unsigned long long* b_bl = (unsigned long long*)((uint8_t*)b_rpos + ((((size_t)N1 / 2 + 1) * 2 + 7) & ~(size_t)7));
     const uint8_t* img = level_ptr(P, L, gray, pyr, frame);
     FinalKp* fin = fin_all + (size_t)frame * P.fin_stride + lv.fin_off;
-    if (a_lds && b_lds) select_harris<NT>(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
-    else if (a_lds) select_harris<NT>(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
-    else if (b_lds) select_harris<NT>(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
-    else select_harris<NT>(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws, s_hw);
+    if (a_lds && b_lds) select_harris<NT>(P, lv, img, s_A, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws, s_hw, L);
+    else if (a_lds) select_harris<NT>(P, lv, img, s_A, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws, s_hw, L);
+    else if (b_lds) select_harris<NT>(P, lv, img, gA, s_B, N1, b_rpos, b_bl, fin, fin_cnt_out, flags, &s_ws, s_hw, L);
+    else select_harris<NT>(P, lv, img, gA, gB, N1, g_rpos, g_bl, fin, fin_cnt_out, flags, &s_ws, s_hw, L);
 }
 
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, int level_hi) {

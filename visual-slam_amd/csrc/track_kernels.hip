@@ -128,7 +128,10 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
     }
     for (int b = tid; b < 257; b += TS_BLOCK) s_bin[b] = s_hist[b];
     __syncthreads();
-    // 4. stable placement of the kept matches: wavefront w owns the distances with d & 3 == w
+    // 4. stable placement of the kept matches: wavefront w owns the distances with d & 3 == w and walks the compacted list 64 keys at a
+    //    time.  A lane finds the lanes of its chunk that hold the SAME distance with nine ballots (one per bit of d: no loop over the
+    //    distinct distances, which cost an LDS round trip each - 11 us of this kernel for one pair); its rank among them plus the bin's
+    //    running count is its slot, and the lowest lane of every group advances that count.
     if (n_keep > 0) {
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int c0 = 0; c0 < n; c0 += 64) {  // (workgroup-uniform trip count)
@@ -136,17 +139,18 @@ __global__ __launch_bounds__(TS_BLOCK) void k_track_select(const mo_keypoint* __
             const uint32_t key = e < n ? keys[e] : 0xFFFFFFFFu;
             const int d = (int)(key >> TS_KEY_BITS);
             const bool mine = e < n && (d & 3) == wv && d < thr;
-            unsigned long long rem = __ballot(mine);
-            while (rem) {  // wave-uniform: one trip per distinct distance among this wavefront's keys of the chunk
-                const int src = __ffsll((long long)rem) - 1;
-                const int dv = __shfl(d, src, 64);
-                const unsigned long long mk = __ballot(mine && d == dv);
-                const int base = s_bin[dv];
-                if (mine && d == dv) sorted[base + __popcll(mk & lt)] = key;
-                if (lane == src) s_bin[dv] = base + __popcll(mk);
-                ts_wave_sync();
-                rem &= ~mk;
+            unsigned long long same = __ballot(mine);
+#pragma unroll
+            for (int b = 2; b < 9; b++) {  // (bits 0 - 1 are the wavefront's: equal for all of its keys)
+                const unsigned long long hb = __ballot((d >> b) & 1);
+                same &= ((d >> b) & 1) ? hb : ~hb;
             }
+            if (mine) {
+                const int base = s_bin[d];
+                sorted[base + __popcll(same & lt)] = key;
+                if ((same & lt) == 0) s_bin[d] = base + __popcll(same);  // (the group's lowest lane; the other lanes read the old count above)
+            }
+            ts_wave_sync();
         }
     }
     __syncthreads();

@@ -47,7 +47,8 @@ struct TvWork {
     unsigned long long* best;  // [pairs] (float32 bits of the MSAC cost << 32) | hypothesis index, minimum wins
     double* norm;      // [pairs][8] fundamental-matrix model: common scale s, centroid 1 (x, y), centroid 2 (x, y) of the
                        // Hartley normalisation x_n = s (x - c); Sampson distances scale by s^2, so thr_n = thr_px * s;
-                       // [5] = max(1, largest |coordinate| in xn) for the error bounds of the float32 stage
+                       // [5] = max(1, largest |coordinate| in xn) for the error bounds of the float32 stage;
+                       // [6] (as 32 bits) = smallest candidate total posted by a k_tv_hyp block of the pair so far
 };
 
 size_t twoview_workspace_bytes(int n_pairs, int cap, int n_hyp) {
@@ -528,7 +529,10 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
     double* xn = w.xn + (size_t)pair * a.cap * 4;
     float* px = w.px + (size_t)pair * a.cap * 4;
     int* qidx = w.qidx + (size_t)pair * a.cap;
-    if (tid == 0) { s_base = 0; w.best[pair] = ~0ull; w.n_alive[pair] = 0; if (pair == 0) *w.n_tasks = 0; }
+    if (tid == 0) {
+        s_base = 0; w.best[pair] = ~0ull; w.n_alive[pair] = 0; if (pair == 0) *w.n_tasks = 0;
+        *(unsigned*)&w.norm[(size_t)pair * 8 + 6] = 0x7F800000u;  // the pair-wide bound of k_tv_hyp's first stage: none yet
+    }
     for (int j = tid; j < (a.n_hyp + 63) / 64; j += TV_BLOCK) w.wkey[(size_t)pair * ((a.n_hyp + 63) / 64) + j] = ~0ull;
     __syncthreads();
     if (a.d_p1) {  // explicit correspondences
@@ -629,8 +633,10 @@ __device__ __forceinline__ double tv_cost_lane(const double* E, const double* xn
 
 __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, int staged, int first_num) {
     __shared__ unsigned long long s_best[TV_BLOCK / 64];
-    const int pair = blockIdx.y, tid = threadIdx.x;
-    const int h = blockIdx.x * TV_BLOCK + tid;
+    // (the blocks of a pair are dispatched side by side; a pair-major grid - a pair's blocks spread over the launch's lifetime so that the
+    //  later ones prune with the earlier ones' bounds - measured slower: 0.397 against 0.385 ms, profiles/r04_ab_tv_bound.txt)
+    const int pair = blockIdx.y, hb = blockIdx.x, tid = threadIdx.x;
+    const int h = hb * TV_BLOCK + tid;
     const int m = w.m[pair];
     if (m < 8) return;
     const double* xn = w.xn + (size_t)pair * a.cap * 4;
@@ -666,9 +672,9 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
         __syncthreads();
         for (int k = 0; k < TV_BLOCK / 64; k++) key = s_best[k] < key ? s_best[k] : key;  // block minimum, in every thread
         if (key != ~0ull && own == key) {  // (a block index is a valid slot: there are at least as many 64-tasks as 256-blocks)
-            double* bE = w.wE + ((size_t)pair * ntask_max + blockIdx.x) * 9;
+            double* bE = w.wE + ((size_t)pair * ntask_max + hb) * 9;
             for (int j = 0; j < 9; j++) bE[j] = E[j];
-            w.wkey[(size_t)pair * ntask_max + blockIdx.x] = key;
+            w.wkey[(size_t)pair * ntask_max + hb] = key;
             atomicMin(&w.best[pair], key);
         }
         return;
@@ -744,7 +750,12 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_hyp(TwoViewArgs a, TvWork w, in
         // this sum is associated differently from the canonical (sequential) one: two float32 ulps upwards cover that
         // and the rounding to float32, so the bound never undercuts the candidate's canonical cost.  A NaN total (the
         // canonical sum of the candidate is then NaN too and it cannot win) gives no bound: everything survives.
-        s_bound = total == total ? __float_as_uint((float)total) + 2u : 0x7F800000u;
+        unsigned bound = total == total ? __float_as_uint((float)total) + 2u : 0x7F800000u;
+        // the bound is pair-wide: every block posts its candidate's total and prunes with the smallest one posted so far (whichever
+        // blocks of the pair got there first - the set of survivors varies from run to run, the minimum over them does not: the best
+        // hypothesis of the pair lies below every candidate's total and always survives).  Non-negative floats order like their bits.
+        const unsigned seen = atomicMin((unsigned*)&w.norm[(size_t)pair * 8 + 6], bound);
+        s_bound = min(bound, seen);
     }
     __syncthreads();
     // survivors (lower bound <= bound; both >= 0, so bit order = value order) -> the pair's dense list in HBM (order is
@@ -1282,7 +1293,8 @@ int twoview_launch(mo_ctx* c, const TwoViewArgs& a_in) {
     }
     const int staged = a.n_hyp >= 512;  // below that the bound of one or two blocks prunes too little to pay for the second stage
     const int first_num = TV_FIRST_NUM;
-    hipLaunchKernelGGL(k_tv_hyp, dim3((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs), dim3(TV_BLOCK), 0, c->stream, a, w, staged, first_num);
+    const dim3 hyp_grid((a.n_hyp + TV_BLOCK - 1) / TV_BLOCK, a.n_pairs);
+    hipLaunchKernelGGL(k_tv_hyp, hyp_grid, dim3(TV_BLOCK), 0, c->stream, a, w, staged, first_num);
     if (staged) {
         const int one_pair = a.n_pairs == 1;
         if (!one_pair) hipLaunchKernelGGL(k_tv_tasks, dim3(1), dim3(TV_BLOCK), 0, c->stream, a, w);

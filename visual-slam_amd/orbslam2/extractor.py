@@ -42,8 +42,13 @@ class _NativeORB:
         return keypoints_from_array(kps)
 
     def compute(self, image, keypoints):
-        kept, desc = vslam_amd.default_context().orb_compute(image, self.prm, keypoints_to_array(keypoints))
-        kept_kps = tuple(keypoints[i] for i in kept)
+        arr = keypoints_to_array(keypoints)
+        kept, desc = vslam_amd.default_context().orb_compute(image, self.prm, arr)
+        from .types import KeyPointSeq
+        if isinstance(keypoints, KeyPointSeq) and keypoints.pristine:
+            kept_kps = KeyPointSeq(arr[kept])                 # records, no objects: the input sequence stays pristine
+        else:
+            kept_kps = tuple(keypoints[i] for i in kept)
         return kept_kps, (desc if len(kept) else None)
 
 

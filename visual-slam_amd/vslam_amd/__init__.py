@@ -15,6 +15,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("VSLAM_AMD_LIB") or os.path.join(_PKG_ROOT, "libvslam_amd.so")
 
 MO_OK, MO_ERR_ARG, MO_ERR_HIP, MO_ERR_CAPACITY, MO_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+ABI_VERSION = 4  # MO_ABI_VERSION of include/vslam_amd.h: the struct layouts mirrored below
 ORDER_LIBSTDCXX, ORDER_MSVC = 0, 1
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "mo_set_stream_null": (_i, [_vp]),
     "mo_sync": (_i, [_vp]),
     "mo_device_count": (_i, []),
+    "mo_abi_version": (_i, []),
     "mo_orb_detect_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mo_orb_compute": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mo_orb_grid_good_features": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -184,6 +186,9 @@ def load_library():
             raise
         fn.restype = res
         fn.argtypes = args
+    if not os.environ.get("VSLAM_AMD_LIB") and lib.mo_abi_version() != ABI_VERSION:
+        raise NativeUnavailable("libvslam_amd.so has ABI version %d, this binding was written for %d: rebuild (make -C visual-slam_amd/csrc)"
+                                % (lib.mo_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 
