@@ -716,33 +716,35 @@ def main():
             #     chunks of 64 through the batched mode with the upload double-buffered - what a driver that can look ahead gets
             from vslam_amd.stream import FrameStream
             host_frames = pl.frames.cpu().numpy()
+            host_frames = np.concatenate([host_frames, host_frames[::-1]] * 4)   # a 2048-frame stack (the pan there and back, four times)
             legs = {}
-            for name, kw in (("track_orb_views", dict(copy=False)), ("track_orb_copies", dict()), ("track_orb_views_iterator", dict(copy=False)),
-                             ("track_grid_views", dict(copy=False, detector=V.DETECT_GRID))):
-                fs = FrameStream(K, width=W, height=H, chunk=64, n_features=NFEAT, cap=CAP, n_hyp=N_HYP, **kw)
+            for name, kw in (("track_orb_chunk64", dict(copy=False)), ("track_orb_chunk128", dict(copy=False, chunk=128)),
+                             ("track_orb_chunk64_copies", dict()), ("track_orb_chunk64_iterator", dict(copy=False)),
+                             ("track_grid_chunk64", dict(copy=False, detector=V.DETECT_GRID))):
+                kw.setdefault("chunk", 64)
+                fs = FrameStream(K, width=W, height=H, n_features=NFEAT, cap=CAP, n_hyp=N_HYP, **kw)
                 try:
                     src = (lambda a: iter(a)) if name.endswith("_iterator") else (lambda a: a)
-                    n_seen = sum(1 for _ in fs.run(src(host_frames[:130])))   # (warm-up: plan, buffers, clocks)
-                    reps = max(2, args.steps // 5)
+                    n_seen = sum(1 for _ in fs.run(src(host_frames[:4 * kw["chunk"] + 2])))   # (warm-up: plan, lanes, clocks)
                     t1 = time.perf_counter()
                     n_seen, n_in = 0, 0
-                    for _ in range(reps):
-                        for r in fs.run(src(host_frames)):
-                            n_seen += 1
-                            p = r.pair                      # (the consumer reads every frame's pose + kept matches and its feature arrays)
-                            if p is not None:
-                                n_in += p["n_inliers"]
+                    for r in fs.run(src(host_frames)):
+                        n_seen += 1
+                        p = r.pair                          # (a tracker's use of a frame: its pose and the kept matches' inlier flags;
+                        if p is not None and p.ok:          #  the feature arrays are there as views, touched for every 16th frame)
+                            n_in += p.n_inliers + int(p.inlier[0]) + (p.R[0, 0] > 2.0)
+                        if (n_seen & 15) == 0:
                             n_in += len(r.keypoints) + len(r.descriptors)
                     el = time.perf_counter() - t1
                 finally:
                     fs.close()
-                legs[name] = {"value": round(n_seen / el, 1), "unit": "frames/s", "frames": n_seen, "ms_per_64_frame_chunk": round(el / n_seen * 64e3, 3)}
-            legs["note"] = ("FrameStream over the bench's own 256 frames as a pageable host frame stack (N, H, W), chunk 64: staging into pinned memory "
-                            "(host threads), H2D on a copy stream, one mo_dev_frontend_batch per chunk in tracking mode (ratio test, 2 filters, 8-pt "
-                            "RANSAC %d hyp at 1 px), results D2H, one Python FrameResult per frame whose pose, kept matches, keypoints and "
-                            "descriptors the loop reads; *_views: result arrays are views of the pinned buffer, *_copies: the caller's own copies; "
-                            "*_iterator: the frames arrive one by one from a Python iterator (gathered into chunks frame by frame); track_grid: "
-                            "the detector Tracker uses by default (distribute_keypoints)" % N_HYP)
+                legs[name] = {"value": round(n_seen / el, 1), "unit": "frames/s", "frames": n_seen, "ms_per_chunk": round(el / n_seen * kw["chunk"] * 1e3, 3)}
+            legs["note"] = ("FrameStream (mo_stream) over a 2048-frame pageable host frame stack (N, H, W) built from the bench's frames, H2D-inclusive: "
+                            "staging into pinned memory (pool of host threads), upload stream, one mo_dev_frontend_batch per chunk in tracking mode "
+                            "(ratio test, 2 filters, 8-pt RANSAC %d hyp at 1 px), download stream, three chunks in flight, one Python FrameResult per "
+                            "frame whose pose and inlier flags the loop reads (feature arrays touched on every 16th frame); result arrays are views of "
+                            "the pinned buffers except in *_copies (the caller's own copies, made per chunk); *_iterator: frames arrive one by one from a "
+                            "Python iterator and are gathered into chunks; track_grid: the detector Tracker uses by default (distribute_keypoints)" % N_HYP)
             out["streaming"] = legs
         out["dev_status"] = dict(status, note="mo_dev_status after every leg's synchronisation: 0 = no capacity flag raised (asserted)")
         if not args.no_cpu_baseline and world == 1:

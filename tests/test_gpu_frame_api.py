@@ -285,3 +285,37 @@ def test_frame_stream_equals_the_per_frame_loop(chunk, detector):
                 assert np.array_equal(p["inlier"], r["inlier"]) and p["n_inliers"] == r["n_inliers"], i
         last = (k, d)
     ctx.close()
+
+
+def test_grid_detector_results_are_resident_too():
+    """ORBExtractor.distribute_keypoints(aligned=True) - Tracker's default detector (tracker.py:87) with keypoint i = descriptor row i -
+    leaves its kept corners and descriptors resident like detect_and_compute: the tracking step on these very arrays takes the token
+    route and equals the upload route; corners / descriptors equal the oracle (extractor.py:85-144)."""
+    import vslam_amd as V
+    from oracle import orb_oracle as O
+    from orbslam2 import utils as geom
+    from orbslam2.extractor import ORBExtractor
+    frames = parallax_frames(3, seed=37, bg_step=3, fg_step=6)
+    # (sensor noise: a noise-free whole-pixel pan gives identical patches, Hamming distance 0 for most matches, a median of 0 and - by the
+    #  reference's strict "distance < 2 x median" - no kept match at all)
+    rng = np.random.Generator(np.random.PCG64(3))
+    frames = np.clip(frames.astype(np.float32) + rng.normal(0, 2.0, frames.shape), 0, 255).round().astype(np.uint8)
+    ex = ORBExtractor(n_features=2000)
+    ctx = V.default_context()
+    out = []
+    for f in frames:
+        kps, desc = ex.distribute_keypoints(f, aligned=True)
+        exy = O.grid_good_features(f, 2000)
+        kin = np.zeros(len(exy), V.KP_DTYPE)
+        kin["x"], kin["y"], kin["size"], kin["angle"], kin["class_id"] = exy[:, 0], exy[:, 1], 31, -1, -1
+        kept, edesc = O.compute(f, O.params(nfeatures=2000), kin)
+        assert np.array_equal(kps.array, kin[kept]) and np.array_equal(desc, edesc) and len(kept) > 300
+        assert V.resident_token(ctx, desc, kps.array) != 0
+        out.append((kps, desc))
+    (k0, d0), (k1, d1), _ = out
+    ok, T, inl = geom.track_from_last_frame(k0, d0, k1, d1, K, frames[0].shape)           # token route: both among the last four results
+    ok2, T2, inl2 = geom.track_from_last_frame(k0, np.array(d0), k1, np.array(d1), K, frames[0].shape)   # copies: upload route
+    assert ok and ok2 and np.array_equal(T, T2) and [(m.queryIdx, m.trainIdx) for m in inl] == [(m.queryIdx, m.trainIdx) for m in inl2]
+    # the reference's own (misaligned) list is unchanged: all corners as KeyPoint objects next to the kept corners' descriptors
+    allk, d_all = ex.distribute_keypoints(frames[0])
+    assert len(allk) >= len(d_all) == len(d0) and np.array_equal(d_all, d0) and allk[0].size == 31 and allk[0].angle == -1

@@ -8,4 +8,4 @@ echo bench done
 bash profiles/collect.sh r04 > $O/collect.log 2>&1; tail -3 $O/collect.log
 bash tools/probe_run.sh r04_probe > $O/probe_run.log 2>&1; tail -20 $O/probe_run.log
 python tools/stream_probe.py 2>&1 | grep chunk | tee $O/r04_stream_probe.txt
-python tools/stream_rate.py 2>&1 | tail -2 | tee $O/r04_stream_rate.txt
+python tools/stream_rate.py 2>&1 | tail -3 | tee $O/r04_stream_rate.txt

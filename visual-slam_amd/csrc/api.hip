@@ -403,42 +403,67 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     if (!c) return MO_ERR_ARG;
     if (!p || !img || !xy || !n_xy || !kept_idx || !desc || !n_kept) return mo_fail(c, MO_ERR_ARG, "NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
+    HostClock clk(c);
     *n_xy = 0; *n_kept = 0;
+    c->last_token = 0;
     if (w < 64 || h < 64 || w > c->max_w || h > c->max_h) return mo_fail(c, MO_ERR_ARG, "image size outside the context limits");
     if (n_features < 64) return mo_fail(c, MO_ERR_ARG, "n_features must be >= 64 (8x8 grid)");
+    if (ch != 1 && ch != 3) return mo_fail(c, MO_ERR_ARG, "ch must be 1 (gray) or 3 (BGR)");
+    if (stride < w * ch) return mo_fail(c, MO_ERR_ARG, "stride smaller than a row");
     int rc = mo_build_plan(c, p, w, h, 1);
     if (rc) return rc;
-    const uint8_t* d_gray = nullptr;
-    if ((rc = stage_images(c, img, w, h, stride, ch, 1, &d_gray))) return rc;
     const int per_cell = n_features / 64, slots = 64 * per_cell;
-    const size_t eig_b = (size_t)w * h * sizeof(float), xy_b = (size_t)slots * 2 * sizeof(float);
-    const size_t o_xy = eig_b, o_n = o_xy + xy_b, o_c2 = o_n + 64 * sizeof(int), o_rec = (o_c2 + 2 * sizeof(int) + 15) & ~(size_t)15;
-    const size_t o_kept = o_rec + (size_t)slots * sizeof(mo_keypoint), o_desc = o_kept + (size_t)slots * sizeof(int32_t);
-    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, o_desc + (size_t)slots * 32))) return rc;
+    // Like the single-frame ORB call (frame_api.hip): the image through pinned staging and the upload kernel, the KEPT keypoints
+    // (KeyPoint(x, y, 31) records, aligned with the descriptor rows) and their descriptors in a resident result slot - mo_last_token
+    // names them for mo_pair_frontend -, everything the caller gets in one region that one small kernel pushes back, one synchronisation.
+    int slot = 0;
+    if ((rc = mo_slot_acquire(c, slots, &slot))) return rc;
+    const int scap = c->slot_cap;
+    mo_keypoint* d_rec = c->d_slot_kps + (size_t)slot * scap;
+    uint8_t* d_desc = c->d_slot_desc + (size_t)slot * scap * 32;
+    int32_t* d_cnt = c->d_slot_cnt + slot;
+    const size_t rowb = (size_t)w * ch, in_bytes = rowb * h, eig_b = (size_t)w * h * sizeof(float), xy_b = (size_t)slots * 2 * sizeof(float);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_eig = take(eig_b), o_out = off, o_fl = take(16), o_xy = take(xy_b), o_n = take(66 * sizeof(int)), o_kept = take((size_t)slots * sizeof(int32_t)),
+                 o_desc = take((size_t)slots * 32), out_end = off;
+    if ((rc = mo_reserve(c, c->d_tmp, c->tmp_bytes, out_end))) return rc;
+    if ((rc = mo_reserve(c, c->d_in, c->d_in_bytes, ((size_t)w * h + 255) & ~(size_t)255))) return rc;
+    const size_t h_out = (in_bytes + 255) & ~(size_t)255;
+    if ((rc = mo_host_stage(c, h_out + (out_end - o_out)))) return rc;
+    uint8_t* hs = c->h_stage;
+    uint8_t* hs_dev = mo_stage_dev(c);
+    if (!hs_dev) return mo_fail(c, MO_ERR_HIP, "the pinned staging buffer is not mapped into the device");
+    if ((size_t)stride == rowb) std::memcpy(hs, img, in_bytes);
+    else for (int y = 0; y < h; y++) std::memcpy(hs + (size_t)y * rowb, img + (size_t)y * stride, rowb);
     uint8_t* b = (uint8_t*)c->d_tmp;
-    float* d_eig = (float*)b; float* d_xy = (float*)(b + o_xy); int* d_n = (int*)(b + o_n); int* d_c2 = (int*)(b + o_c2);
-    mo_keypoint* d_rec = (mo_keypoint*)(b + o_rec); int32_t* d_kept = (int32_t*)(b + o_kept); uint8_t* d_desc = b + o_desc;
+    float* d_eig = (float*)(b + o_eig); float* d_xy = (float*)(b + o_xy); int* d_n = (int*)(b + o_n);
+    int32_t* d_kept = (int32_t*)(b + o_kept);
     c->flags_cur = host_flags(c);
-    HIPCHK(c, hipMemsetAsync(host_flags(c), 0, 4 * sizeof(int), c->stream));
     mo_stage_begin(c);
+    if ((rc = orb_launch_ingest(c, hs_dev, w, h, ch, c->d_in, host_flags(c)))) return rc;
+    mo_stage_mark(c, "h2d");
+    const uint8_t* d_gray = c->d_in;
     if ((rc = gftt_launch(c, d_gray, w, h, n_features, d_eig, d_xy, d_n))) return rc;
-    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, d_rec, d_kept, slots, nullptr, 1))) return rc;  // (d_c2 = d_n + 64)
+    if ((rc = gftt_records_launch(c, d_xy, d_n, per_cell, w, h, p->edge_threshold, d_rec, d_kept, scap, d_cnt, 1))) return rc;  // (totals: d_n[64], d_n[65])
     mo_stage_mark(c, "grid_good_features");
     if ((rc = orb_launch_blur(c, d_gray, 1, 1, 0))) return rc;  // the records all sit on octave 0
-    if ((rc = orb_launch_describe_given(c, d_gray, d_rec, slots, d_desc, d_c2 + 1, 1, 0))) return rc;
+    if ((rc = orb_launch_describe_given(c, d_gray, d_rec, slots, d_desc, d_n + 65, 1, 0))) return rc;
     mo_stage_mark(c, "compute");
-    // everything back through the pinned staging buffer behind one synchronisation
-    const size_t h_xy = 16, h_n = h_xy + xy_b, h_kept = h_n + 66 * sizeof(int), h_desc = h_kept + (size_t)slots * sizeof(int32_t);
-    if ((rc = host_stage(c, h_desc + (size_t)slots * 32))) return rc;
-    uint8_t* hs = c->h_stage;
-    HIPCHK(c, hipMemcpyAsync(hs, host_flags(c), 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hs + h_xy, d_xy, xy_b, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hs + h_n, d_n, 66 * sizeof(int), hipMemcpyDeviceToHost, c->stream));  // 64 cell counts + the two totals
-    HIPCHK(c, hipMemcpyAsync(hs + h_kept, d_kept, (size_t)slots * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(hs + h_desc, d_desc, (size_t)slots * 32, hipMemcpyDeviceToHost, c->stream));
+    // descriptors of the kept corners and the flag words into the result region, then the region into the pinned buffer
+    HIPCHK(c, hipMemcpyAsync(b + o_desc, d_desc, (size_t)slots * 32, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b + o_fl, host_flags(c), 16, hipMemcpyDeviceToDevice, c->stream));
+    mo_copy_out_launch(c, b + o_out, hs_dev + h_out, out_end - o_out);
+    HIPCHK(c, hipGetLastError());
+    mo_stage_mark(c, "d2h");
+    clk.enqueued();
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const int* hn = (const int*)(hs + h_n);
-    const float* hxy = (const float*)(hs + h_xy);
+    clk.waited();
+    const uint8_t* ho = hs + h_out;
+    const int* hn = (const int*)(ho + (o_n - o_out));
+    const float* hxy = (const float*)(ho + (o_xy - o_out));
+    const int fl = *(const int*)(ho + (o_fl - o_out));
+    if (fl & 2) return mo_fail(c, MO_ERR_CAPACITY, "more grid corners than the result slot holds");
     int n = 0;
     for (int cell = 0; cell < 64; cell++)
         for (int i = 0; i < std::min(hn[cell], per_cell); i++, n++) {
@@ -448,8 +473,9 @@ extern "C" int mo_orb_grid_detect_compute(mo_ctx* c, const mo_orb_params* p, con
     const int nk = hn[65];
     if (hn[64] != n || nk < 0 || nk > n) return mo_fail(c, MO_ERR_HIP, "grid corner counts disagree between host and device");
     *n_xy = n; *n_kept = nk;
-    std::memcpy(kept_idx, hs + h_kept, (size_t)nk * sizeof(int32_t));
-    std::memcpy(desc, hs + h_desc, (size_t)nk * 32);
+    std::memcpy(kept_idx, ho + (o_kept - o_out), (size_t)nk * sizeof(int32_t));
+    std::memcpy(desc, ho + (o_desc - o_out), (size_t)nk * 32);
+    mo_slot_commit(c, slot, nk);
     return MO_OK;
 }
 

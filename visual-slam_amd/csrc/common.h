@@ -193,6 +193,11 @@ int mo_run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int
 int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch, mo_keypoint* kps,
                      uint8_t* desc, int cap, int* counts);
 
+int mo_slot_acquire(mo_ctx* c, int rows, int* slot);   // frame_api.hip: resident result slots for the other single-frame entry points
+uint64_t mo_slot_commit(mo_ctx* c, int slot, int n);
+uint8_t* mo_stage_dev(mo_ctx* c);                       // device address of the pinned staging buffer
+void mo_copy_out_launch(mo_ctx* c, const void* d_src, void* h_dst_dev, size_t bytes);  // device -> pinned staging, one small kernel
+
 // stage timing helpers (hipEvents on the context stream)
 void mo_stage_begin(mo_ctx* c);
 void mo_stage_mark(mo_ctx* c, const char* name);

@@ -18,9 +18,11 @@
 
 static inline size_t al(size_t v, size_t a) { return (v + a - 1) & ~(a - 1); }
 
-// (re)allocates the slot arrays for rows of `cap` records; a change of cap invalidates every token (the row stride is the cap)
+// (re)allocates the slot arrays when rows of `cap` records do not fit; growing them invalidates every token (the row stride is the cap).
+// Callers use c->slot_cap - not their own cap - as the row stride afterwards.
 static int slots_reserve(mo_ctx* c, int cap) {
-    if (c->d_slot_kps && c->slot_cap == cap) return MO_OK;
+    if (c->d_slot_kps && c->slot_cap >= cap) return MO_OK;
+    cap = (int)al((size_t)cap, 16);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     void* old[] = {c->d_slot_kps, c->d_slot_desc, c->d_slot_cnt, c->d_slot_ids};
     for (void* b : old) if (b) hipFree(b);
@@ -54,6 +56,26 @@ static int next_slot(mo_ctx* c, int keep) {
     c->slot_cur = s;
     c->slot_token[s] = 0;
     return s;
+}
+
+// for the other single-frame entry points (api.hip: the grid detector): a free slot with rows for `rows` records -> its index; commit
+// names the records written into it (n of them) with a fresh token
+int mo_slot_acquire(mo_ctx* c, int rows, int* slot) {
+    int rc = slots_reserve(c, rows);
+    if (rc) return rc;
+    *slot = next_slot(c, -1);
+    return MO_OK;
+}
+uint64_t mo_slot_commit(mo_ctx* c, int slot, int n) {
+    c->slot_n[slot] = n;
+    c->slot_token[slot] = c->token_next++;
+    c->last_token = c->slot_token[slot];
+    return c->last_token;
+}
+uint8_t* mo_stage_dev(mo_ctx* c) {
+    void* d = nullptr;
+    if (!c->h_stage || hipHostGetDevicePointer(&d, c->h_stage, 0) != hipSuccess) return nullptr;
+    return (uint8_t*)d;
 }
 
 // device -> pinned host, valid rows only: out = [flags 4 x i32][count, cap, 0, 0][kps cap x 28 B, padded to 16][desc cap x 32 B]
@@ -90,10 +112,11 @@ __global__ __launch_bounds__(256) void k_copy_out(const uint4* __restrict__ src,
     if (t < n16) dst[t] = src[t];
 }
 
-static uint8_t* stage_dev(mo_ctx* c) {
-    void* d = nullptr;
-    if (hipHostGetDevicePointer(&d, c->h_stage, 0) != hipSuccess) return nullptr;
-    return (uint8_t*)d;
+static uint8_t* stage_dev(mo_ctx* c) { return mo_stage_dev(c); }
+
+void mo_copy_out_launch(mo_ctx* c, const void* d_src, void* h_dst_dev, size_t bytes) {
+    const int n16 = (int)((bytes + 15) / 16);
+    hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, c->stream, (const uint4*)d_src, (uint4*)h_dst_dev, n16);
 }
 
 int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int w, int h, int stride, int ch, mo_keypoint* kps,
@@ -107,8 +130,9 @@ int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int 
     int rc = mo_build_plan(c, p, w, h, 1);  // validates sizes before any staging
     if (rc) return rc;
     if ((rc = slots_reserve(c, cap))) return rc;
+    const int scap = c->slot_cap;  // row stride of the slot arrays (>= cap: the kernels write up to scap rows, the caller gets up to cap)
     const size_t row = (size_t)w * ch, in_bytes = row * h, o_out = al(in_bytes, 256);
-    const size_t o_kps = 32, o_desc = o_kps + al((size_t)cap * 28, 16), out_bytes = o_desc + (size_t)cap * 32;
+    const size_t o_kps = 32, o_desc = o_kps + al((size_t)scap * 28, 16), out_bytes = o_desc + (size_t)scap * 32;
     if ((rc = mo_host_stage(c, o_out + out_bytes))) return rc;
     if ((rc = mo_reserve(c, c->d_in, c->d_in_bytes, al((size_t)w * h, 256)))) return rc;
     uint8_t* hs = c->h_stage;
@@ -117,14 +141,14 @@ int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int 
     if ((size_t)stride == row) std::memcpy(hs, img, in_bytes);
     else for (int y = 0; y < h; y++) std::memcpy(hs + (size_t)y * row, img + (size_t)y * stride, row);
     const int slot = next_slot(c, -1);
-    mo_keypoint* d_k = c->d_slot_kps + (size_t)slot * cap;
-    uint8_t* d_d = c->d_slot_desc + (size_t)slot * cap * 32;
+    mo_keypoint* d_k = c->d_slot_kps + (size_t)slot * scap;
+    uint8_t* d_d = c->d_slot_desc + (size_t)slot * scap * 32;
     int32_t* d_n = c->d_slot_cnt + slot;
     mo_stage_begin(c);
     if ((rc = orb_launch_ingest(c, hs_dev, w, h, ch, c->d_in, mo_host_flags(c)))) return rc;
-    if ((rc = mo_run_extract(c, p, c->d_in, w, h, 1, d_k, desc ? d_d : nullptr, cap, d_n, 2))) return rc;
-    hipLaunchKernelGGL(k_pack_out, dim3((unsigned)((cap * 9 + 255) / 256)), dim3(256), 0, c->stream, d_k, desc ? d_d : (const uint8_t*)nullptr, d_n,
-                       mo_host_flags(c), hs_dev + o_out, cap);
+    if ((rc = mo_run_extract(c, p, c->d_in, w, h, 1, d_k, desc ? d_d : nullptr, scap, d_n, 2))) return rc;
+    hipLaunchKernelGGL(k_pack_out, dim3((unsigned)((scap * 9 + 255) / 256)), dim3(256), 0, c->stream, d_k, desc ? d_d : (const uint8_t*)nullptr, d_n,
+                       mo_host_flags(c), hs_dev + o_out, scap);
     HIPCHK(c, hipGetLastError());
     mo_stage_mark(c, "d2h");
     clk.enqueued();
@@ -134,7 +158,7 @@ int mo_detect_single(mo_ctx* c, const mo_orb_params* p, const uint8_t* img, int 
     const int fl = ho[0], total = ho[4];
     counts[0] = total;  // MO_ERR_CAPACITY: counts already holds the size a retry needs
     if (fl & 1) { c->tie_overflow = true; c->tie_levels = ho[1]; return mo_fail(c, MO_ERR_CAPACITY, "internal per-level keypoint capacity exceeded (response ties)"); }
-    if (fl & 2) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
+    if ((fl & 2) || total > cap) return mo_fail(c, MO_ERR_CAPACITY, "more keypoints than cap; counts holds the required sizes");
     const int n = std::min(std::max(total, 0), cap);
     if (n > 0) {
         std::memcpy(kps, hs + o_out + o_kps, (size_t)n * sizeof(mo_keypoint));

@@ -78,16 +78,18 @@ class ORBExtractor:
         (maxCorners = n_features // 64, qualityLevel 0.01, minDistance 10), KeyPoint(x, y, 31) each, then
         orb.compute on all of them.  Like the reference, the returned list holds ALL corners while the descriptor
         rows are those cv2 keeps (corners within 31 px of the border are dropped by compute).
-        aligned=True (an extension, not in the reference): only the kept corners are returned, so that keypoint i belongs to
-        descriptor row i - what a caller needs to index keypoints with match indices."""
+        aligned=True (an extension, not in the reference): only the kept corners are returned - as a lazy KeyPointSeq, like
+        detect_and_compute - so that keypoint i belongs to descriptor row i: what a caller needs to index keypoints with match indices."""
         if n_features is None:
             n_features = self.n_features
         image = np.asarray(image)
         # corners, KeyPoint(x, y, 31) records of the ones orb.compute keeps, and their descriptors in ONE device call
         # (mo_orb_grid_detect_compute: one upload, one synchronisation; the records never exist as Python objects)
+        if aligned:  # the kept corners as a record sequence, resident on the device with their descriptors (like detect_and_compute)
+            from .types import KeyPointSeq
+            _, kept, descriptors, rec = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features, records=True)
+            return KeyPointSeq(rec), (descriptors if len(kept) else None)
         xy, kept, descriptors = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features)
-        if aligned:
-            xy = xy[kept]
         all_keypoints = keypoints_at(xy, 31)  # a list, like the reference's (bulk conversion, slots filled directly)
         if not len(kept):
             descriptors = None

@@ -383,20 +383,33 @@ class Context:
         self._check(self.lib.mo_orb_grid_good_features(self.h, _ptr(a), w, h, w * ch, ch, int(n_features), _ptr(xy), C.byref(n)))
         return xy[:n.value].copy()
 
-    def grid_detect_compute(self, image, prm, n_features):
+    def grid_detect_compute(self, image, prm, n_features, records=False):
         """ORBExtractor.distribute_keypoints in one device call -> (xy (N,2) float32 of ALL corners, kept (M,) int32 indices into xy
-        of the corners orb.compute keeps, desc (M,32) uint8)"""
+        of the corners orb.compute keeps, desc (M,32) uint8).  records=True: a fourth value, the KeyPoint(x, y, 31) records of the kept
+        corners (KP_DTYPE, aligned with desc) - they and desc stay resident on the device like a detect_and_compute result (pair steps
+        on these very arrays upload nothing)."""
         a = np.ascontiguousarray(image, dtype=np.uint8)
         ch = 3 if a.ndim == 3 else 1
         h, w = a.shape[0], a.shape[1]
         slots = 64 * max(int(n_features) // 64, 1)
-        xy = np.zeros((slots, 2), np.float32)
-        kept = np.zeros(slots, np.int32)
-        desc = np.zeros((slots, 32), np.uint8)
+        xy = np.empty((slots, 2), np.float32)
+        kept = np.empty(slots, np.int32)
+        desc = np.empty((slots, 32), np.uint8)
         n, nk = C.c_int(0), C.c_int(0)
         self._check(self.lib.mo_orb_grid_detect_compute(self.h, C.byref(prm), _ptr(a), w, h, w * ch, ch, int(n_features), _ptr(xy),
                                                         C.byref(n), _ptr(kept), _ptr(desc), C.byref(nk)))
-        return xy[:n.value].copy(), kept[:nk.value].copy(), desc[:nk.value].copy()
+        xy, kept, desc = xy[:n.value], kept[:nk.value], desc[:nk.value]
+        if not records:
+            return xy, kept, desc
+        rec = np.zeros(nk.value, KP_DTYPE)
+        rec["x"], rec["y"] = xy[kept, 0], xy[kept, 1]
+        rec["size"], rec["angle"], rec["class_id"] = 31.0, -1.0, -1
+        tok = C.c_uint64(0)
+        self.lib.mo_last_token(self.h, C.byref(tok))
+        self.last_token = int(tok.value)
+        if self.last_token and nk.value:
+            _bind_resident(self, self.last_token, rec, desc)
+        return xy, kept, desc, rec
 
     def undistort(self, image, K, dist):
         """cv2.undistort(image, K, dist): (H, W) or (H, W, 3) uint8 -> same shape"""
