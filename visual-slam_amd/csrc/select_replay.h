@@ -507,11 +507,11 @@ __device__ __forceinline__ void wave_reg_introselect(P a, int first, int nth, in
     wave_sync();
 }
 
+// continuation of libstdc++'s __introselect on [first, last) with `depth` rounds left before the heap-select fallback; all 64 lanes of ONE
+// wavefront, convergent, no workgroup barrier
 template <class T, class P>
-__device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int lane) {
+__device__ __forceinline__ void wave_ls_introselect(P a, int first, int nth, int last, int depth, uint16_t* rpos, unsigned long long* bl, int lane) {
     typedef Rec<T> R;
-    if (first == last || nth == last) return;
-    int depth = (31 - __clz(last - first)) * 2;
     while (last - first > 3) {
         if (last - first <= REPLAY_REG_MAX) { wave_reg_introselect<T>(a, first, nth, last, depth, lane); return; }
         if (last - first > 65535 || depth == 0) {
@@ -532,6 +532,12 @@ __device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int
     }
     if (lane == 0) ls_insertion_sort<T>(a, first, last);
     wave_sync();
+}
+
+template <class T, class P>
+__device__ __forceinline__ void wave_ls_nth_element(P a, int first, int nth, int last, uint16_t* rpos, unsigned long long* bl, int lane) {
+    if (first == last || nth == last) return;
+    wave_ls_introselect<T>(a, first, nth, last, (31 - __clz(last - first)) * 2, rpos, bl, lane);
 }
 
 // retainBest, all lanes convergent.  libstdc++ order runs wave-parallel; the MSVC STL's three-way partition is
@@ -727,8 +733,11 @@ __device__ __forceinline__ void wg_ls_nth_element(P a, int first, int nth, int l
     if (first == last || nth == last) return;
     int depth = (31 - __clz(last - first)) * 2;
     while (last - first > 3) {
-        if (last - first <= REPLAY_REG_MAX) {  // the rest on the registers of one wavefront
-            if (tid < 64) wave_reg_introselect<T>(a, first, nth, last, depth, tid);
+        // below the cooperative partition's range the REST of the selection runs on wavefront 0 alone (its own partition rounds, then
+        // the register-resident tail): the other wavefronts wait at ONE barrier instead of three per round (a round on 65 .. 383 records
+        // cost 4.5 k cycles with 16 wavefronts at its barriers, profiles/r04_replay_rounds_single_frame.txt)
+        if (last - first < WG_PARTITION_MIN) {
+            if (tid < 64) wave_ls_introselect<T>(a, first, nth, last, depth, rpos, bl, tid);
             __syncthreads();
             return;
         }
