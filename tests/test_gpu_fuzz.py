@@ -39,3 +39,12 @@ def test_random_configurations_of_the_geometry_calls_equal_the_oracle(capsys):
     out = capsys.readouterr().out
     assert rc == 0 and "MISMATCH" not in out, out[-2000:]
     assert " 0 with a mismatch" in out
+
+
+def test_random_sequences_streamed_equal_the_per_frame_loop(capsys):
+    """tools/fuzz_frames.py: FrameStream against the single-frame calls with pair_index (token, upload and stale-token routes), the fused
+    initialisation step against matcher + two-view call - random sizes, detectors, chunk sizes, sequence lengths"""
+    rc = _tool("fuzz_frames").main(["--n", "40", "--seed", "14", "--budget-s", "120"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "MISMATCH" not in out and "refused" not in out, out[-2000:]
+    assert " 0 with a mismatch" in out
