@@ -607,7 +607,9 @@ __global__ __launch_bounds__(TV_BLOCK) void k_tv_prep(TwoViewArgs a, TvWork w) {
 // ---------------------------------------------------------------- hypotheses ----------------------
 
 // correspondences summed by the first scoring stage: TV_FIRST_NUM eighths of them, at least 32
+#ifndef TV_FIRST_NUM
 #define TV_FIRST_NUM 2
+#endif
 __device__ __forceinline__ int tv_first(int m, int num) { return min(m, max(32, (m * num + 7) >> 3)); }
 
 // ---- THE CANONICAL MSAC COST (the value the keys are defined on): the correspondences are cut into TV_PARTS contiguous parts of

@@ -52,14 +52,19 @@ class MapInitializer:
         img = self.first_frame_image
         h, w = img.shape[:2]
         xy = np.trunc(points_of(keypoints, query_indices).astype(np.float64)).astype(np.int64)
+        px, py = xy[:, 0], xy[:, 1]
+        inside = (px >= 0) & (px < w) & (py >= 0) & (py < h)
+        if inside.all():   # (always, for keypoints the extractor produced: they keep 31 px from the border) one gather instead of a loop
+            rows = img[py, px] if img.ndim == 3 else np.repeat(img[py, px][:, None], 3, axis=1)
+            return list(rows)
         colours = []
-        for px, py in xy.tolist():
-            if not (0 <= px < w and 0 <= py < h):
+        for x, y, ok in zip(px.tolist(), py.tolist(), inside.tolist()):
+            if not ok:
                 colours.append(np.array([0, 0, 255]))
             elif img.ndim == 3:
-                colours.append(img[py, px, :])
+                colours.append(img[y, x, :])
             else:
-                colours.append(np.array([img[py, px]] * 3))
+                colours.append(np.array([img[y, x]] * 3))
         return colours
 
     def _device_pair(self, ref_kps, ref_desc, cur_kps, cur_desc, matcher):
