@@ -399,6 +399,8 @@ int mo_host_times(mo_ctx*, double us[4]);
 int mo_set_host_timing(mo_ctx*, int on);
 
 /* internal-stage probes used by the parity tests (device pipeline, host in/out) */
+/* blurred: bit 0 = the blurred level instead of the raw one; bit 1 = through the single-frame kernel (pyramid + blur in one launch,
+   the route of calls on one or two frames) instead of the batched path's kernels: MO_ERR_UNSUPPORTED for a geometry it does not cover */
 int mo_dbg_pyramid_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level, int blurred,
                          uint8_t* out /* lw*lh */, int* lw, int* lh);
 int mo_dbg_fast_level(mo_ctx*, const mo_orb_params*, const uint8_t* gray, int w, int h, int level,

@@ -68,13 +68,21 @@ int mo_run_extract(mo_ctx* c, const mo_orb_params* p, const uint8_t* d_gray, int
     const int blur_margin = (c->plan.edge_threshold - 19) & ~3, pyr_margin = std::max(blur_margin - 4, 0);
     // (one frame of a host call: the finest level's FAST + selection on a second stream beside the pyramid and the other levels was
     //  measured in round 4 - no gain, level 1's chain is as long as level 0's: profiles/r04_ab_single_split.txt)
-    if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels, pyr_margin))) return rc;
-    mo_stage_mark(c, "pyramid");
-    // the Gaussian blur only depends on the pyramid: in line, right behind it (an aux-stream fork beside FAST + selection gained <= 1 %
-    // in the BATCHED mode in rounds 1 - 2 and was retired there: profiles/r02_ab_serial_blur.txt)
-    if (d_desc) {
-        if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin))) return rc;
-        mo_stage_mark(c, "blur");
+    if (batch <= MO_FS_MAX_BATCH && c->fs_ok) {
+        // one or two frames: pyramid and blur in ONE launch whose workgroups chain the levels of their own tile through LDS
+        // (front_single.hip; the seven dependent resize launches + the blur were 62 of 202 us of a one-frame call)
+        if ((rc = orb_launch_front_single(c, d_gray, batch, d_desc != nullptr))) return rc;
+        mo_stage_mark(c, "pyramid");
+        if (d_desc) mo_stage_mark(c, "blur");  // (inside the same launch: the stage keeps its name, its time is in "pyramid")
+    } else {
+        if ((rc = orb_launch_pyramid(c, d_gray, batch, c->plan.nlevels, pyr_margin))) return rc;
+        mo_stage_mark(c, "pyramid");
+        // the Gaussian blur only depends on the pyramid: in line, right behind it (an aux-stream fork beside FAST + selection gained <= 1 %
+        // in the BATCHED mode in rounds 1 - 2 and was retired there: profiles/r02_ab_serial_blur.txt)
+        if (d_desc) {
+            if ((rc = orb_launch_blur(c, d_gray, batch, c->plan.nlevels, blur_margin))) return rc;
+            mo_stage_mark(c, "blur");
+        }
     }
     if ((rc = orb_launch_fast(c, d_gray, batch))) return rc;
     mo_stage_mark(c, "fast_nms");
@@ -855,11 +863,18 @@ extern "C" int mo_dbg_pyramid_level(mo_ctx* c, const mo_orb_params* p, const uin
     if (level < 0 || level >= c->plan.nlevels) return mo_fail(c, MO_ERR_ARG, "level out of range");
     const uint8_t* d_gray = nullptr;
     if ((rc = stage_images(c, gray, w, h, w, 1, 1, &d_gray))) return rc;
-    if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
+    const bool fused = (blurred & 2) != 0;  // bit 1: through the single-frame kernel (front_single.hip) instead of k_resize2 / k_blur
+    blurred &= 1;
+    if (fused) {
+        if (!c->fs_ok) return mo_fail(c, MO_ERR_UNSUPPORTED, "the single-frame pyramid kernel does not cover this geometry");
+        HIPCHK(c, hipMemsetAsync(c->d_pyr, 0xA5, (size_t)c->plan.pyr_stride, c->stream));   // whatever it does not write shows
+        HIPCHK(c, hipMemsetAsync(c->d_blur, 0xA5, (size_t)c->plan.blur_stride, c->stream));
+        if ((rc = orb_launch_front_single(c, d_gray, 1, 1))) return rc;
+    } else if ((rc = orb_launch_pyramid(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
     const LevelInfo& v = c->plan.lv[level];
     *lw = v.w; *lh = v.h;
     if (blurred) {
-        if ((rc = orb_launch_blur(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
+        if (!fused && (rc = orb_launch_blur(c, d_gray, 1, c->plan.nlevels, 0))) return rc;
         HIPCHK(c, hipMemcpy2DAsync(out, v.w, c->d_blur + v.boff, v.bpitch, v.w, v.h, hipMemcpyDeviceToHost, c->stream));
     } else {
         const uint8_t* src = level == 0 ? d_gray : c->d_pyr + v.off;

@@ -103,6 +103,7 @@ struct mo_ctx {
     uint32_t* d_tile_tab[2] = {nullptr, nullptr};          // blur: tile -> level | tile column << 8 | tile row << 20 (built with the plan); [0]: whole levels, [1]: without the margin tile_margin
     int tile_cum[2][MO_MAX_LEVELS + 1] = {};               // tiles of levels < L (the tables are level-major: a prefix blurs the first levels)
     int tile_margin = 0;
+    uint32_t* d_fs_tab = nullptr; int fs_tiles = 0, fs_stride = 0, fs_lds = 0; bool fs_ok = false;  // k_front_single: per-tile headers + coefficient slices (built with the plan)
     uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
     uint32_t* d_dtile_tab = nullptr; int n_dtiles = 0, dtile_icw_off = 0;  // k_describe_tiles: tile -> level | column << 8 | row << 20, then the centroid weights
     int* d_dtodo = nullptr; size_t dtodo_bytes = 0;  // k_describe_tiles -> k_describe_tiles_rare: [0] count, then frame * tiles + tile
@@ -209,6 +210,12 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch);
 int orb_launch_gray(mo_ctx* c, const uint8_t* d_bgr, int w, int h, int batch, uint8_t* d_gray);
 int orb_launch_ingest(mo_ctx* c, const uint8_t* src_mapped, int w, int h, int ch, uint8_t* d_gray, int* flags_clear);
 int orb_launch_pyramid(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
+// front_single.hip: pyramid + blur of a few frames in ONE launch (single-frame calls); fs_build runs with the plan and leaves
+// c->fs_ok false for geometries it does not cover, which keep orb_launch_pyramid + orb_launch_blur
+#define MO_FS_MAX_BATCH 2
+int fs_build(mo_ctx* c);
+int orb_launch_front_single(mo_ctx* c, const uint8_t* d_gray, int batch, int want_blur);
+void mo_linear_coeffs(int srcsize, int dstsize, std::vector<int>& ofs, std::vector<int>& c1);
 int orb_launch_blur(mo_ctx* c, const uint8_t* d_gray, int batch, int nlevels, int margin);
 int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);
 int orb_launch_select(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo = 0, int level_hi = MO_MAX_LEVELS);

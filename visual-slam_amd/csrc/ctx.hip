@@ -84,6 +84,8 @@ static void free_plan_buffers(mo_ctx* c) {
     }
     void* bufs[] = {c->d_pyr, c->d_blur, c->d_cand, c->d_strip_cnt, c->d_scratch, c->d_fin, c->d_fin_cnt, c->d_tile_tab[0], c->d_tile_tab[1], c->d_strip_tab, c->d_dtile_tab};
     c->d_dtile_tab = nullptr; c->n_dtiles = 0;
+    if (c->d_fs_tab) hipFree(c->d_fs_tab);
+    c->d_fs_tab = nullptr; c->fs_ok = false;
     for (void* b : bufs) if (b) hipFree(b);
     c->d_tile_tab[0] = c->d_tile_tab[1] = nullptr; c->d_strip_tab = nullptr; c->n_strip_tab = 0;
     c->d_pyr = c->d_blur = nullptr; c->d_cand = nullptr; c->d_strip_cnt = nullptr; c->d_scratch = nullptr;
@@ -168,7 +170,7 @@ extern "C" int mo_stage_times(mo_ctx* c, const char*** names, float* ms, int cap
 
 // INTER_LINEAR_EXACT coefficient table of one axis (interpolationLinear<ufixedpoint16>::getCoeffs):
 // offset + the weight of the right/lower neighbour in 1/256 units (left weight = 256 - c1).
-static void linear_coeffs(int srcsize, int dstsize, std::vector<int>& ofs, std::vector<int>& c1) {
+void mo_linear_coeffs(int srcsize, int dstsize, std::vector<int>& ofs, std::vector<int>& c1) {
     ofs.assign(dstsize, 0);
     c1.assign(dstsize, 0);
     double inv_scale = (double)dstsize / (double)srcsize;
@@ -317,8 +319,8 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
     // resize tables
     for (int L = 1; L < nl; L++) {
         std::vector<int> xo, xc, yo, yc;
-        linear_coeffs(P.lv[L - 1].w, P.lv[L].w, xo, xc);
-        linear_coeffs(P.lv[L - 1].h, P.lv[L].h, yo, yc);
+        mo_linear_coeffs(P.lv[L - 1].w, P.lv[L].w, xo, xc);
+        mo_linear_coeffs(P.lv[L - 1].h, P.lv[L].h, yo, yc);
         const int dw = P.lv[L].w, dh = P.lv[L].h, wp = ((dw + 63) & ~63) + 64, hp = ((dh + 63) & ~63) + 64;  // + 64: the tiling may start at a margin
         auto pack = [](const std::vector<int>& o, const std::vector<int>& c1, int srcsize, int padded) {
             std::vector<uint32_t> t((size_t)padded);
@@ -363,6 +365,10 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         return mo_fail(c, MO_ERR_HIP, "hipMalloc of the final-keypoint slots failed: " + std::to_string(B * P.fin_stride * sizeof(FinalKp)) +
                                           " bytes (" + std::to_string(batch) + " frames x " + std::to_string(P.fin_stride) + " slots; slots grow with response ties)");
     HIPCHK(c, hipMalloc((void**)&c->d_fin_cnt, B * MO_MAX_LEVELS * sizeof(int)));
+    {
+        const int rc_fs = fs_build(c);  // single-frame pyramid + blur kernel: tile boxes of this plan
+        if (rc_fs) return rc_fs;
+    }
     c->batch_alloc = batch;
     c->plan_params = *p;
     c->plan_valid = true;

@@ -1,0 +1,313 @@
+// Pyramid + Gaussian blur of ONE frame (or a few) in one launch: the single-frame form of orb_launch_pyramid + orb_launch_blur.
+//
+// A host call on one 640x480 frame spent 62 of its 202 us of GPU time between the upload and FAST in seven dependent k_resize2
+// launches and one k_blur (4 - 5 us each for a few tiles of work, plus 4 us of queue starvation after each of the last five: the
+// host cannot enqueue as fast as these kernels end; profiles/r04_single_frame_timeline_detect.txt).  The levels depend on one
+// another, so one launch needs either device-wide barriers between the levels or no exchange between workgroups at all.  This
+// kernel takes the second way: a workgroup owns one tile of EVERY level (the same fraction of each level's columns and rows) and
+// builds the chain level 0 -> 1 -> ... in LDS, recomputing the few pixels beside its tile that its own next level and its own blur
+// read (INTER_LINEAR_EXACT is a function of the source pixels alone, so a recomputed pixel equals the neighbour's: the level-0
+// halo is about 25 px at 8 levels of 1.2).  The arithmetic is k_resize2's and k_blur's, value for value (same packed coefficient
+// entries, same u16 row interpolants / row sums, same rounding); the batched path keeps those kernels, whose tiles are sized for
+// chip-wide throughput, and any geometry this kernel's boxes do not fit keeps them too (fs_build leaves fs_ok false).
+//
+// Reference: cv2.ORB's pyramid (resize of the previous level, INTER_LINEAR_EXACT) and GaussianBlur(7x7, sigma 2, REFLECT_101)
+// behind /root/reference/src/orbslam2/extractor.py:50-67 (detectAndCompute).
+#include "common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#define FS_NT 1024
+#define FS_COLS 32                    // quads per pass of a row: thread -> (row = tid / 32, quad = tid % 32)
+#define FS_ROWS (FS_NT / FS_COLS)
+#define FS_BOX_INTS 12
+#define FS_HDR_INTS (MO_MAX_LEVELS * FS_BOX_INTS + 4)
+#define FS_MAX_LDS (144 * 1024)       // of the 160 KB of a gfx950 CU (the static header lives there too)
+
+// one level of one tile (FS_BOX_INTS ints in the tile's header)
+struct FsBox {
+    int ex0, ey0;            // origin of the extended box in level coordinates (ex0 is a multiple of 4)
+    int ew, eh;              // its size; ew (a multiple of 4) is the LDS row pitch
+    int ox0, oy0, ox1, oy1;  // own box [ox0, ox1) x [oy0, oy1): the pixels this workgroup stores (ox0 a multiple of 4; ox1 too, or the level width)
+    int a_off;               // byte offset of the level's pixels in LDS
+    int t_off;               // dword offset (inside the tile's coefficient block) of ew column entries followed by eh row entries (levels >= 1)
+    int r_off;               // u16 offset (inside the row-sum block) of (oy1 - oy0 + 6) rows x ow4 columns
+    int ow4;                 // own width rounded up to a multiple of 4
+};
+
+static inline int fs_reflect(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// Builds the per-tile headers and coefficient slices of the current plan (c->d_fs_tab).  Leaves c->fs_ok false - the callers then
+// take orb_launch_pyramid / orb_launch_blur - when there is nothing to fuse or a tile does not fit in LDS.
+int fs_build(mo_ctx* c) {
+    c->fs_ok = false;
+    if (c->d_fs_tab) { hipFree(c->d_fs_tab); c->d_fs_tab = nullptr; }
+    const Plan& P = c->plan;
+    const int nl = P.nlevels;
+    if (nl < 2) return MO_OK;
+    std::vector<std::vector<int>> xo(nl), xc(nl), yo(nl), yc(nl);
+    for (int L = 1; L < nl; L++) {
+        mo_linear_coeffs(P.lv[L - 1].w, P.lv[L].w, xo[L], xc[L]);
+        mo_linear_coeffs(P.lv[L - 1].h, P.lv[L].h, yo[L], yc[L]);
+    }
+    const LevelInfo& top = P.lv[nl - 1];
+    if (top.w < 8 || top.h < 8) return MO_OK;
+    // tiles of about 64 x 60 level-0 pixels, and never narrower than 8 pixels on the coarsest level
+    const int nx = std::max(1, std::min((P.w + 32) / 64, top.w / 8)), ny = std::max(1, std::min((P.h + 30) / 60, top.h / 8));
+    const int ntiles = nx * ny;
+    auto X = [&](int L, int i) { return i >= nx ? P.lv[L].w : (int)(((long long)i * P.lv[L].w / nx) & ~3ll); };
+    auto Y = [&](int L, int j) { return j >= ny ? P.lv[L].h : (int)((long long)j * P.lv[L].h / ny); };
+
+    std::vector<std::vector<uint32_t>> blobs((size_t)ntiles);
+    size_t max_ints = 0, max_lds = 0;
+    for (int ty = 0; ty < ny; ty++)
+        for (int tx = 0; tx < nx; tx++) {
+            FsBox b[MO_MAX_LEVELS] = {};
+            for (int L = nl - 1; L >= 0; L--) {
+                const int W = P.lv[L].w, H = P.lv[L].h;
+                FsBox& v = b[L];
+                v.ox0 = X(L, tx); v.ox1 = X(L, tx + 1); v.oy0 = Y(L, ty); v.oy1 = Y(L, ty + 1);
+                if (v.ox1 - v.ox0 < 4 || v.oy1 - v.oy0 < 4) return MO_OK;  // (cannot happen with the tile counts above)
+                v.ow4 = ((v.ox1 + 3) & ~3) - v.ox0;
+                // what the blur of the own box reads (REFLECT_101 at the level border)
+                int lx = W, hx = -1, ly = H, hy = -1;
+                for (int x = v.ox0 - 3; x < v.ox1 + 3; x++) { const int r = fs_reflect(x, W); lx = std::min(lx, r); hx = std::max(hx, r); }
+                for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); ly = std::min(ly, r); hy = std::max(hy, r); }
+                if (L + 1 < nl) {  // what the next level's extended box (all of it is computed, padding columns included) reads
+                    const FsBox& n = b[L + 1];
+                    const int W1 = P.lv[L + 1].w;
+                    const int x0 = std::min(n.ex0, W1 - 1), x1 = std::min(n.ex0 + n.ew - 1, W1 - 1);
+                    lx = std::min(lx, xo[L + 1][x0]); hx = std::max(hx, std::min(xo[L + 1][x1] + 1, W - 1));
+                    const int y0 = n.ey0, y1 = n.ey0 + n.eh - 1;
+                    ly = std::min(ly, yo[L + 1][y0]); hy = std::max(hy, std::min(yo[L + 1][y1] + 1, H - 1));
+                }
+                v.ex0 = lx & ~3; v.ew = ((hx + 1 + 3) & ~3) - v.ex0;
+                v.ey0 = ly; v.eh = hy + 1 - ly;
+            }
+            // LDS layout: pixels of every level | coefficient entries | blur row sums
+            size_t off = 0;
+            for (int L = 0; L < nl; L++) { b[L].a_off = (int)off; off += ((size_t)b[L].ew * b[L].eh + 15) & ~(size_t)15; }
+            const size_t tab_base = off;
+            int nt = 0;
+            for (int L = 1; L < nl; L++) { b[L].t_off = nt; nt += b[L].ew + ((b[L].eh + 3) & ~3); }  // 16-byte aligned slices (uint4 reads)
+            off += (((size_t)nt * 4) + 15) & ~(size_t)15;
+            const size_t rs_base = off;
+            int nr = 0;
+            for (int L = 0; L < nl; L++) { b[L].r_off = nr; nr += ((b[L].oy1 - b[L].oy0 + 6) * b[L].ow4 + 3) & ~3; }
+            off += (size_t)nr * 2;
+            max_lds = std::max(max_lds, off);
+
+            std::vector<uint32_t>& blob = blobs[(size_t)ty * nx + tx];
+            blob.assign((size_t)FS_HDR_INTS + nt, 0u);
+            for (int L = 0; L < nl; L++) std::memcpy(&blob[(size_t)L * FS_BOX_INTS], &b[L], sizeof(FsBox));
+            blob[MO_MAX_LEVELS * FS_BOX_INTS + 0] = (uint32_t)nt;
+            blob[MO_MAX_LEVELS * FS_BOX_INTS + 1] = (uint32_t)tab_base;
+            blob[MO_MAX_LEVELS * FS_BOX_INTS + 2] = (uint32_t)rs_base;
+            // coefficient entries in k_resize2's packing, source offsets relative to the previous level's extended box; every source
+            // index is checked against that box here, so the kernel's LDS reads need no bounds test
+            for (int L = 1; L < nl; L++) {
+                const FsBox& v = b[L];
+                const FsBox& s = b[L - 1];
+                const int W = P.lv[L].w, SW = P.lv[L - 1].w, SH = P.lv[L - 1].h;
+                uint32_t* e = &blob[(size_t)FS_HDR_INTS + v.t_off];
+                for (int i = 0; i < v.ew; i++) {
+                    const int j = std::min(v.ex0 + i, W - 1), o = xo[L][j], o1 = std::min(o + 1, SW - 1), rel = o - s.ex0;
+                    if (rel < 0 || rel + (o1 - o) >= s.ew || rel > 0x7FFF) return MO_OK;
+                    e[i] = (uint32_t)rel | ((uint32_t)(o1 - o) << 15) | ((uint32_t)xc[L][j] << 16);
+                }
+                for (int i = 0; i < v.eh; i++) {
+                    const int j = v.ey0 + i, o = yo[L][j], o1 = std::min(o + 1, SH - 1), rel = o - s.ey0;
+                    if (rel < 0 || rel + (o1 - o) >= s.eh || rel > 0x7FFF) return MO_OK;
+                    e[v.ew + i] = (uint32_t)rel | ((uint32_t)(o1 - o) << 15) | ((uint32_t)yc[L][j] << 16);
+                }
+            }
+            // the blur's reads against the box of the level itself
+            for (int L = 0; L < nl; L++) {
+                const FsBox& v = b[L];
+                const int W = P.lv[L].w, H = P.lv[L].h;
+                for (int x = v.ox0 - 3; x < v.ox1 + 3; x++) { const int r = fs_reflect(x, W); if (r < v.ex0 || r >= v.ex0 + v.ew) return MO_OK; }
+                for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); if (r < v.ey0 || r >= v.ey0 + v.eh) return MO_OK; }
+            }
+            max_ints = std::max(max_ints, blob.size());
+        }
+    if (max_lds > FS_MAX_LDS) return MO_OK;
+    const size_t stride = (max_ints + 3) & ~(size_t)3;
+    std::vector<uint32_t> all(stride * ntiles, 0u);
+    for (int t = 0; t < ntiles; t++) std::copy(blobs[t].begin(), blobs[t].end(), all.begin() + (size_t)t * stride);
+    HIPCHK(c, hipMalloc((void**)&c->d_fs_tab, all.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy(c->d_fs_tab, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->fs_tiles = ntiles;
+    c->fs_stride = (int)stride;
+    c->fs_lds = (int)max_lds;
+    c->fs_ok = true;
+    return MO_OK;
+}
+
+typedef unsigned short fs_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t fs_udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(fs_u16x2, a), __builtin_bit_cast(fs_u16x2, b), c, false);
+}
+__device__ __forceinline__ int fs_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, const uint32_t* __restrict__ tab, int stride,
+                                                        const uint8_t* __restrict__ gray, uint8_t* __restrict__ pyr,
+                                                        uint8_t* __restrict__ blur, int want_blur) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ int s_hdr[FS_HDR_INTS];
+    const int tid = threadIdx.x, frame = blockIdx.y, nl = P.nlevels;
+    const uint32_t* blob = tab + (size_t)blockIdx.x * stride;
+    if (tid < FS_HDR_INTS) s_hdr[tid] = (int)blob[tid];
+    __syncthreads();
+    const FsBox* box = (const FsBox*)s_hdr;
+    const int nt = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS], tab_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 1],
+              rs_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 2];
+    uint32_t* s_tab = (uint32_t*)(lds + tab_base);
+    const int rr0 = tid / FS_COLS, cq0 = tid % FS_COLS;
+
+    // ---- level 0: the extended box out of the frame, and the coefficient entries of all levels, in one round trip
+    {
+        const FsBox b = box[0];
+        const uint8_t* g = gray + (size_t)frame * P.w * P.h;
+        const int qw = b.ew >> 2;
+        if ((P.w & 3) == 0 && (((size_t)g) & 3) == 0) {  // (then the box ends inside the row: its right edge is a multiple of 4 <= w)
+            for (int r = rr0; r < b.eh; r += FS_ROWS)
+                for (int q = cq0; q < qw; q += FS_COLS)
+                    ((uint32_t*)(lds + b.a_off + r * b.ew))[q] = *(const uint32_t*)(g + (size_t)(b.ey0 + r) * P.w + b.ex0 + 4 * q);
+        } else {
+            for (int r = rr0; r < b.eh; r += FS_ROWS)
+                for (int q = cq0; q < qw; q += FS_COLS) {
+                    const uint8_t* row = g + (size_t)(b.ey0 + r) * P.w;
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(b.ex0 + 4 * q + k, P.w - 1)] << (8 * k);
+                    ((uint32_t*)(lds + b.a_off + r * b.ew))[q] = v;
+                }
+        }
+        for (int i = tid; i < nt; i += FS_NT) s_tab[i] = blob[FS_HDR_INTS + i];
+    }
+    __syncthreads();
+
+    // ---- levels 1 .. : INTER_LINEAR_EXACT from the previous level's box in LDS (k_resize2's arithmetic: row interpolants
+    //      (256 - cx) a + cx b < 2^16, then ((256 - cy) h0 + cy h1 + 32768) >> 16); the own part goes to the pyramid slab
+    for (int L = 1; L < nl; L++) {
+        const FsBox b = box[L];
+        const int spitch = box[L - 1].ew;
+        const uint8_t* A0 = lds + box[L - 1].a_off;
+        uint8_t* A = lds + b.a_off;
+        const uint32_t* xt = s_tab + b.t_off;
+        const uint32_t* yt = xt + b.ew;
+        const LevelInfo lv = P.lv[L];
+        uint8_t* dst = pyr + (size_t)frame * P.pyr_stride + lv.off;
+        const int qw = b.ew >> 2;
+        for (int r = rr0; r < b.eh; r += FS_ROWS) {
+            const uint32_t ye = yt[r], cy1 = ye >> 16, cy = (256u - cy1) | (cy1 << 16);
+            const uint8_t* r0 = A0 + (ye & 0x7FFFu) * spitch;
+            const uint8_t* r1 = r0 + ((ye >> 15) & 1u) * spitch;
+            const int y = b.ey0 + r;
+            for (int q = cq0; q < qw; q += FS_COLS) {
+                const uint4 xe4 = *(const uint4*)(xt + 4 * q);
+                const uint32_t xe[4] = {xe4.x, xe4.y, xe4.z, xe4.w};
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t o = xe[k] & 0x7FFFu, o1 = o + ((xe[k] >> 15) & 1u), c1 = xe[k] >> 16, c0 = 256u - c1;
+                    const uint32_t h0 = c0 * r0[o] + c1 * r0[o1], h1 = c0 * r1[o] + c1 * r1[o1];
+                    const uint32_t v = fs_udot2(h0 | (h1 << 16), cy, 32768u);
+                    packed |= ((v >> 16) & 0xFFu) << (8 * k);
+                }
+                ((uint32_t*)(A + r * b.ew))[q] = packed;
+                const int x = b.ex0 + 4 * q;
+                // pitch is a multiple of 16 >= w: the <= 3 bytes past w of the last own quad land in row padding
+                if (y >= b.oy0 && y < b.oy1 && x >= b.ox0 && x < b.ox1) *(uint32_t*)(dst + (size_t)y * lv.pitch + x) = packed;
+            }
+        }
+        __syncthreads();
+    }
+    if (!want_blur) return;
+
+    // ---- 7x7 Gaussian of the own boxes of all levels (k_blur's arithmetic: u16 row sums of 8-bit taps, column sums + 2^15, >> 16,
+    //      saturated).  Row pass: own rows - 3 .. + 3 (REFLECT_101), own columns
+    const uint32_t g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];
+    unsigned short* s_rs = (unsigned short*)(lds + rs_base);
+    for (int L = 0; L < nl; L++) {
+        const FsBox b = box[L];
+        const int W = P.lv[L].w, H = P.lv[L].h;
+        const int nrows = b.oy1 - b.oy0 + 6, qw = b.ow4 >> 2;
+        const uint8_t* A = lds + b.a_off;
+        unsigned short* R = s_rs + b.r_off;
+        const uint32_t ta = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), tb = g2 | (g1 << 8) | (g0 << 16);
+        for (int rr = rr0; rr < nrows; rr += FS_ROWS) {
+            const int y = fs_reflect101(b.oy0 - 3 + rr, H);
+            const uint8_t* row = A + (y - b.ey0) * b.ew - b.ex0;  // indexed by level column
+            for (int q = cq0; q < qw; q += FS_COLS) {
+                const int x0 = b.ox0 + 4 * q;
+                uint32_t o[4];
+                if (x0 >= 4 && x0 + 6 < W) {  // taps x0 - 3 .. x0 + 6 inside the level: three aligned dwords from column x0 - 4
+                    const uint32_t* pw = (const uint32_t*)(row + x0 - 4);
+                    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+                    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tb, 0, false), false);
+                    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tb, 0, false), false);
+                    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tb, 0, false), false);
+                    o[3] = __builtin_amdgcn_udot4(w1, ta, __builtin_amdgcn_udot4(w2, tb, 0, false), false);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t s = 0;
+                        if (x0 + k < W) {
+#pragma unroll
+                            for (int t = 0; t < 7; t++) s += (uint32_t)P.gk[t] * row[fs_reflect101(x0 + k - 3 + t, W)];
+                        }
+                        o[k] = s;
+                    }
+                }
+                *(uint2*)(R + rr * b.ow4 + 4 * q) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));  // each sum <= 257 * 255
+            }
+        }
+    }
+    __syncthreads();
+    for (int L = 0; L < nl; L++) {
+        const FsBox b = box[L];
+        const LevelInfo lv = P.lv[L];
+        const int oh = b.oy1 - b.oy0, qw = b.ow4 >> 2;
+        const unsigned short* R = s_rs + b.r_off;
+        uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff;
+        for (int r = rr0; r < oh; r += FS_ROWS)
+            for (int q = cq0; q < qw; q += FS_COLS) {
+                uint32_t s[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    const uint2 v = *(const uint2*)(R + (r + t) * b.ow4 + 4 * q);
+                    const uint32_t g = (uint32_t)P.gk[t];
+                    s[0] += g * (v.x & 0xFFFFu); s[1] += g * (v.x >> 16); s[2] += g * (v.y & 0xFFFFu); s[3] += g * (v.y >> 16);
+                }
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) packed |= min(s[k] >> 16, 255u) << (8 * k);
+                // bpitch is a multiple of 16 >= w: the <= 3 bytes past w land in row padding
+                *(uint32_t*)(out + (size_t)(b.oy0 + r) * lv.bpitch + b.ox0 + 4 * q) = packed;
+            }
+    }
+}
+
+// pyramid levels 1.. and (want_blur) the blurred levels 0.. of `batch` frames; the caller has checked c->fs_ok
+int orb_launch_front_single(mo_ctx* c, const uint8_t* d_gray, int batch, int want_blur) {
+    if (!c->fs_ok || !c->d_fs_tab) return mo_fail(c, MO_ERR_ARG, "front_single: no tile table for this plan");
+    if (!(c->lds_attr_done & 64u)) {
+        HIPCHK(c, hipFuncSetAttribute((const void*)k_front_single, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_LDS));
+        c->lds_attr_done |= 64u;
+    }
+    hipLaunchKernelGGL(k_front_single, dim3((unsigned)c->fs_tiles, (unsigned)batch), dim3(FS_NT), (size_t)c->fs_lds, c->stream, c->plan,
+                       c->d_fs_tab, c->fs_stride, d_gray, c->d_pyr, c->d_blur, want_blur);
+    HIPCHK(c, hipGetLastError());
+    return MO_OK;
+}
