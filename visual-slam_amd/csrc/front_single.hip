@@ -20,9 +20,7 @@
 #include <vector>
 
 #define FS_NT 1024
-#define FS_COLS 32                    // quads per pass of a row: thread -> (row = tid / 32, quad = tid % 32)
-#define FS_ROWS (FS_NT / FS_COLS)
-#define FS_BOX_INTS 12
+#define FS_BOX_INTS 14
 #define FS_HDR_INTS (MO_MAX_LEVELS * FS_BOX_INTS + 4)
 #define FS_MAX_LDS (144 * 1024)       // of the 160 KB of a gfx950 CU (the static header lives there too)
 
@@ -35,6 +33,7 @@ struct FsBox {
     int t_off;               // dword offset (inside the tile's coefficient block) of ew column entries followed by eh row entries (levels >= 1)
     int r_off;               // u16 offset (inside the row-sum block) of (oy1 - oy0 + 6) rows x ow4 columns
     int ow4;                 // own width rounded up to a multiple of 4
+    uint32_t inv_e, inv_o;   // floor(2^20 / (ew / 4)) + 1 and floor(2^20 / (ow4 / 4)) + 1: task -> (row, quad) without a division
 };
 
 static inline int fs_reflect(int p, int len) {
@@ -75,20 +74,27 @@ int fs_build(mo_ctx* c) {
                 v.ox0 = X(L, tx); v.ox1 = X(L, tx + 1); v.oy0 = Y(L, ty); v.oy1 = Y(L, ty + 1);
                 if (v.ox1 - v.ox0 < 4 || v.oy1 - v.oy0 < 4) return MO_OK;  // (cannot happen with the tile counts above)
                 v.ow4 = ((v.ox1 + 3) & ~3) - v.ox0;
-                // what the blur of the own box reads (REFLECT_101 at the level border)
-                int lx = W, hx = -1, ly = H, hy = -1;
-                for (int x = v.ox0 - 3; x < v.ox1 + 3; x++) { const int r = fs_reflect(x, W); lx = std::min(lx, r); hx = std::max(hx, r); }
+                // what the blur of the own box reads.  Columns: own - 3 .. own + 2 as they are; on the level's left / right border these are
+                // the pad columns -3 .. -1 / W .. W + 2, which the kernel fills with the REFLECT_101 pixels once the level is complete, so
+                // that every quad of the row pass reads three aligned dwords (a lane on a per-tap reflection path held its whole wavefront
+                // 16 x longer: 27 of this kernel's first 49 us, profiles/r04_front_single_stamps.txt).  Rows: reflected per row.
+                int lx = v.ox0 - 3, hx = v.ox1 + 2, ly = H, hy = -1;
+                if (v.ox0 > 0 && lx < 0) return MO_OK;
+                if (v.ox1 < W && hx > W - 1) return MO_OK;
                 for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); ly = std::min(ly, r); hy = std::max(hy, r); }
                 if (L + 1 < nl) {  // what the next level's extended box (all of it is computed, padding columns included) reads
                     const FsBox& n = b[L + 1];
                     const int W1 = P.lv[L + 1].w;
-                    const int x0 = std::min(n.ex0, W1 - 1), x1 = std::min(n.ex0 + n.ew - 1, W1 - 1);
+                    const int x0 = std::min(std::max(n.ex0, 0), W1 - 1), x1 = std::min(std::max(n.ex0 + n.ew - 1, 0), W1 - 1);  // (pad columns take the border column's entry)
                     lx = std::min(lx, xo[L + 1][x0]); hx = std::max(hx, std::min(xo[L + 1][x1] + 1, W - 1));
                     const int y0 = n.ey0, y1 = n.ey0 + n.eh - 1;
                     ly = std::min(ly, yo[L + 1][y0]); hy = std::max(hy, std::min(yo[L + 1][y1] + 1, H - 1));
                 }
-                v.ex0 = lx & ~3; v.ew = ((hx + 1 + 3) & ~3) - v.ex0;
+                v.ex0 = lx & ~3; v.ew = ((hx + 1 + 3) & ~3) - v.ex0;  // (-3 & ~3 == -4)
                 v.ey0 = ly; v.eh = hy + 1 - ly;
+                v.inv_e = (1u << 20) / (uint32_t)(v.ew >> 2) + 1u; v.inv_o = (1u << 20) / (uint32_t)(v.ow4 >> 2) + 1u;
+                // (row, quad) of task i as (i * inv) >> 20: exact while i * quads < 2^20
+                if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20) || (long long)(v.oy1 - v.oy0 + 6) * (v.ow4 >> 2) * (v.ow4 >> 2) >= (1 << 20)) return MO_OK;
             }
             // LDS layout: pixels of every level | coefficient entries | blur row sums
             size_t off = 0;
@@ -117,7 +123,7 @@ int fs_build(mo_ctx* c) {
                 const int W = P.lv[L].w, SW = P.lv[L - 1].w, SH = P.lv[L - 1].h;
                 uint32_t* e = &blob[(size_t)FS_HDR_INTS + v.t_off];
                 for (int i = 0; i < v.ew; i++) {
-                    const int j = std::min(v.ex0 + i, W - 1), o = xo[L][j], o1 = std::min(o + 1, SW - 1), rel = o - s.ex0;
+                    const int j = std::min(std::max(v.ex0 + i, 0), W - 1), o = xo[L][j], o1 = std::min(o + 1, SW - 1), rel = o - s.ex0;
                     if (rel < 0 || rel + (o1 - o) >= s.ew || rel > 0x7FFF) return MO_OK;
                     e[i] = (uint32_t)rel | ((uint32_t)(o1 - o) << 15) | ((uint32_t)xc[L][j] << 16);
                 }
@@ -131,7 +137,8 @@ int fs_build(mo_ctx* c) {
             for (int L = 0; L < nl; L++) {
                 const FsBox& v = b[L];
                 const int W = P.lv[L].w, H = P.lv[L].h;
-                for (int x = v.ox0 - 3; x < v.ox1 + 3; x++) { const int r = fs_reflect(x, W); if (r < v.ex0 || r >= v.ex0 + v.ew) return MO_OK; }
+                for (int x = v.ox0 - 4; x < v.ox0 + v.ow4 + 3; x++) if (x < v.ex0 || (x >= v.ex0 + v.ew && x < std::min(v.ox1 + 3, W + 3))) return MO_OK;
+                if ((v.ox0 == 0 || v.ox1 == W) && W < 8) return MO_OK;
                 for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); if (r < v.ey0 || r >= v.ey0 + v.eh) return MO_OK; }
             }
             max_ints = std::max(max_ints, blob.size());
@@ -153,11 +160,6 @@ typedef unsigned short fs_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t fs_udot2(uint32_t a, uint32_t b, uint32_t c) {
     return __builtin_amdgcn_udot2(__builtin_bit_cast(fs_u16x2, a), __builtin_bit_cast(fs_u16x2, b), c, false);
 }
-__device__ __forceinline__ int fs_reflect101(int p, int len) {
-    if (len == 1) return 0;
-    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
-}
 
 __global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, const uint32_t* __restrict__ tab, int stride,
                                                         const uint8_t* __restrict__ gray, uint8_t* __restrict__ pyr,
@@ -172,26 +174,26 @@ __global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, const uint32_t* 
     const int nt = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS], tab_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 1],
               rs_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 2];
     uint32_t* s_tab = (uint32_t*)(lds + tab_base);
-    const int rr0 = tid / FS_COLS, cq0 = tid % FS_COLS;
+    // Every pass below is one loop over the (row, quad) tasks of a box, task i -> row (i * inv) >> 20 (host reciprocal): the phases
+    // are bound by instruction issue, and a fixed thread -> column mapping left a fifth to a half of the lanes without a task.
 
     // ---- level 0: the extended box out of the frame, and the coefficient entries of all levels, in one round trip
     {
         const FsBox b = box[0];
         const uint8_t* g = gray + (size_t)frame * P.w * P.h;
-        const int qw = b.ew >> 2;
-        if ((P.w & 3) == 0 && (((size_t)g) & 3) == 0) {  // (then the box ends inside the row: its right edge is a multiple of 4 <= w)
-            for (int r = rr0; r < b.eh; r += FS_ROWS)
-                for (int q = cq0; q < qw; q += FS_COLS)
-                    ((uint32_t*)(lds + b.a_off + r * b.ew))[q] = *(const uint32_t*)(g + (size_t)(b.ey0 + r) * P.w + b.ex0 + 4 * q);
-        } else {
-            for (int r = rr0; r < b.eh; r += FS_ROWS)
-                for (int q = cq0; q < qw; q += FS_COLS) {
-                    const uint8_t* row = g + (size_t)(b.ey0 + r) * P.w;
-                    uint32_t v = 0;
+        const int qw = b.ew >> 2, n = qw * b.eh;
+        const bool al = (P.w & 3) == 0 && (((size_t)g) & 3) == 0;  // (then a quad lies inside the row or in a pad)
+        for (int i = tid; i < n; i += FS_NT) {
+            const int r = (int)(((uint32_t)i * b.inv_e) >> 20), q = i - r * qw, x = b.ex0 + 4 * q;
+            const uint8_t* row = g + (size_t)(b.ey0 + r) * P.w;
+            uint32_t v = 0;
+            if (al) {
+                if (x >= 0 && x < P.w) v = *(const uint32_t*)(row + x);  // (pad quads are filled once the levels are complete)
+            } else {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(b.ex0 + 4 * q + k, P.w - 1)] << (8 * k);
-                    ((uint32_t*)(lds + b.a_off + r * b.ew))[q] = v;
-                }
+                for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(x + k, 0), P.w - 1)] << (8 * k);
+            }
+            ((uint32_t*)(lds + b.a_off + r * b.ew))[q] = v;
         }
         for (int i = tid; i < nt; i += FS_NT) s_tab[i] = blob[FS_HDR_INTS + i];
     }
@@ -208,94 +210,95 @@ __global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, const uint32_t* 
         const uint32_t* yt = xt + b.ew;
         const LevelInfo lv = P.lv[L];
         uint8_t* dst = pyr + (size_t)frame * P.pyr_stride + lv.off;
-        const int qw = b.ew >> 2;
-        for (int r = rr0; r < b.eh; r += FS_ROWS) {
+        const int qw = b.ew >> 2, n = qw * b.eh;
+        for (int i = tid; i < n; i += FS_NT) {
+            const int r = (int)(((uint32_t)i * b.inv_e) >> 20), q = i - r * qw;
             const uint32_t ye = yt[r], cy1 = ye >> 16, cy = (256u - cy1) | (cy1 << 16);
             const uint8_t* r0 = A0 + (ye & 0x7FFFu) * spitch;
             const uint8_t* r1 = r0 + ((ye >> 15) & 1u) * spitch;
-            const int y = b.ey0 + r;
-            for (int q = cq0; q < qw; q += FS_COLS) {
-                const uint4 xe4 = *(const uint4*)(xt + 4 * q);
-                const uint32_t xe[4] = {xe4.x, xe4.y, xe4.z, xe4.w};
-                uint32_t packed = 0;
+            const uint4 xe4 = *(const uint4*)(xt + 4 * q);
+            const uint32_t xe[4] = {xe4.x, xe4.y, xe4.z, xe4.w};
+            uint32_t packed = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t o = xe[k] & 0x7FFFu, o1 = o + ((xe[k] >> 15) & 1u), c1 = xe[k] >> 16, c0 = 256u - c1;
-                    const uint32_t h0 = c0 * r0[o] + c1 * r0[o1], h1 = c0 * r1[o] + c1 * r1[o1];
-                    const uint32_t v = fs_udot2(h0 | (h1 << 16), cy, 32768u);
-                    packed |= ((v >> 16) & 0xFFu) << (8 * k);
-                }
-                ((uint32_t*)(A + r * b.ew))[q] = packed;
-                const int x = b.ex0 + 4 * q;
-                // pitch is a multiple of 16 >= w: the <= 3 bytes past w of the last own quad land in row padding
-                if (y >= b.oy0 && y < b.oy1 && x >= b.ox0 && x < b.ox1) *(uint32_t*)(dst + (size_t)y * lv.pitch + x) = packed;
+            for (int k = 0; k < 4; k++) {
+                const uint32_t o = xe[k] & 0x7FFFu, o1 = o + ((xe[k] >> 15) & 1u), c1 = xe[k] >> 16, c0 = 256u - c1;
+                const uint32_t h0 = c0 * r0[o] + c1 * r0[o1], h1 = c0 * r1[o] + c1 * r1[o1];
+                const uint32_t v = fs_udot2(h0 | (h1 << 16), cy, 32768u);
+                packed |= ((v >> 16) & 0xFFu) << (8 * k);
             }
+            ((uint32_t*)(A + r * b.ew))[q] = packed;
+            const int x = b.ex0 + 4 * q, y = b.ey0 + r;
+            // pitch is a multiple of 16 >= w: the <= 3 bytes past w of the last own quad land in row padding
+            if (y >= b.oy0 && y < b.oy1 && x >= b.ox0 && x < b.ox1) *(uint32_t*)(dst + (size_t)y * lv.pitch + x) = packed;
         }
         __syncthreads();
     }
     if (!want_blur) return;
 
+    // ---- pad columns of the boxes on a level's left / right border: REFLECT_101 (column -k = column k, column W - 1 + k = W - 1 - k)
+    for (int L = 0; L < nl; L++) {
+        const FsBox b = box[L];
+        const int W = P.lv[L].w;
+        const bool left = b.ox0 == 0, right = b.ox1 == W;
+        if (!left && !right) continue;  // block-uniform
+        uint8_t* A = lds + b.a_off - b.ex0;  // indexed by level column
+        for (int r = tid; r < b.eh; r += FS_NT) {
+            uint8_t* row = A + r * b.ew;
+            if (left) { row[-1] = row[1]; row[-2] = row[2]; row[-3] = row[3]; }
+            if (right) { row[W] = row[W - 2]; row[W + 1] = row[W - 3]; row[W + 2] = row[W - 4]; }
+        }
+    }
+    __syncthreads();
+
     // ---- 7x7 Gaussian of the own boxes of all levels (k_blur's arithmetic: u16 row sums of 8-bit taps, column sums + 2^15, >> 16,
-    //      saturated).  Row pass: own rows - 3 .. + 3 (REFLECT_101), own columns
+    //      saturated).  Row pass: own rows - 3 .. + 3 (REFLECT_101 per row), own columns; the 7 taps of four adjacent outputs are
+    //      two v_dot4 each on byte windows cut out of three aligned dwords (columns x0 - 4 .. x0 + 7)
     const uint32_t g0 = P.gk[0], g1 = P.gk[1], g2 = P.gk[2], g3 = P.gk[3];
+    const uint32_t ta = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), tb = g2 | (g1 << 8) | (g0 << 16);
     unsigned short* s_rs = (unsigned short*)(lds + rs_base);
     for (int L = 0; L < nl; L++) {
         const FsBox b = box[L];
-        const int W = P.lv[L].w, H = P.lv[L].h;
-        const int nrows = b.oy1 - b.oy0 + 6, qw = b.ow4 >> 2;
-        const uint8_t* A = lds + b.a_off;
+        const int H = P.lv[L].h;
+        const int qw = b.ow4 >> 2, n = (b.oy1 - b.oy0 + 6) * qw;
+        const uint8_t* A = lds + b.a_off - b.ex0 + b.ox0 - 4;  // column x0 - 4 of quad 0
         unsigned short* R = s_rs + b.r_off;
-        const uint32_t ta = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24), tb = g2 | (g1 << 8) | (g0 << 16);
-        for (int rr = rr0; rr < nrows; rr += FS_ROWS) {
-            const int y = fs_reflect101(b.oy0 - 3 + rr, H);
-            const uint8_t* row = A + (y - b.ey0) * b.ew - b.ex0;  // indexed by level column
-            for (int q = cq0; q < qw; q += FS_COLS) {
-                const int x0 = b.ox0 + 4 * q;
-                uint32_t o[4];
-                if (x0 >= 4 && x0 + 6 < W) {  // taps x0 - 3 .. x0 + 6 inside the level: three aligned dwords from column x0 - 4
-                    const uint32_t* pw = (const uint32_t*)(row + x0 - 4);
-                    const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
-                    o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tb, 0, false), false);
-                    o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tb, 0, false), false);
-                    o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tb, 0, false), false);
-                    o[3] = __builtin_amdgcn_udot4(w1, ta, __builtin_amdgcn_udot4(w2, tb, 0, false), false);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        uint32_t s = 0;
-                        if (x0 + k < W) {
-#pragma unroll
-                            for (int t = 0; t < 7; t++) s += (uint32_t)P.gk[t] * row[fs_reflect101(x0 + k - 3 + t, W)];
-                        }
-                        o[k] = s;
-                    }
-                }
-                *(uint2*)(R + rr * b.ow4 + 4 * q) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));  // each sum <= 257 * 255
-            }
+        for (int i = tid; i < n; i += FS_NT) {
+            const int rr = (int)(((uint32_t)i * b.inv_o) >> 20), q = i - rr * qw;
+            int y = b.oy0 - 3 + rr;
+            y = y < 0 ? -y : y;
+            y = y >= H ? 2 * H - 2 - y : y;
+            const uint32_t* pw = (const uint32_t*)(A + (y - b.ey0) * b.ew + 4 * q);
+            const uint32_t w0 = pw[0], w1 = pw[1], w2 = pw[2];
+            // output k is centred on byte k + 4 of (w0, w1, w2): taps over bytes k + 1 .. k + 7
+            const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), tb, 0, false), false);
+            const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), tb, 0, false), false);
+            const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), ta, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), tb, 0, false), false);
+            const uint32_t o3 = __builtin_amdgcn_udot4(w1, ta, __builtin_amdgcn_udot4(w2, tb, 0, false), false);
+            *(uint2*)(R + rr * b.ow4 + 4 * q) = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));  // each sum <= 257 * 255
         }
     }
     __syncthreads();
     for (int L = 0; L < nl; L++) {
         const FsBox b = box[L];
         const LevelInfo lv = P.lv[L];
-        const int oh = b.oy1 - b.oy0, qw = b.ow4 >> 2;
+        const int qw = b.ow4 >> 2, n = (b.oy1 - b.oy0) * qw;
         const unsigned short* R = s_rs + b.r_off;
         uint8_t* out = blur + (size_t)frame * P.blur_stride + lv.boff;
-        for (int r = rr0; r < oh; r += FS_ROWS)
-            for (int q = cq0; q < qw; q += FS_COLS) {
-                uint32_t s[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
+        for (int i = tid; i < n; i += FS_NT) {
+            const int r = (int)(((uint32_t)i * b.inv_o) >> 20), q = i - r * qw;
+            uint32_t s[4] = {1u << 15, 1u << 15, 1u << 15, 1u << 15};
 #pragma unroll
-                for (int t = 0; t < 7; t++) {
-                    const uint2 v = *(const uint2*)(R + (r + t) * b.ow4 + 4 * q);
-                    const uint32_t g = (uint32_t)P.gk[t];
-                    s[0] += g * (v.x & 0xFFFFu); s[1] += g * (v.x >> 16); s[2] += g * (v.y & 0xFFFFu); s[3] += g * (v.y >> 16);
-                }
-                uint32_t packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) packed |= min(s[k] >> 16, 255u) << (8 * k);
-                // bpitch is a multiple of 16 >= w: the <= 3 bytes past w land in row padding
-                *(uint32_t*)(out + (size_t)(b.oy0 + r) * lv.bpitch + b.ox0 + 4 * q) = packed;
+            for (int t = 0; t < 7; t++) {
+                const uint2 v = *(const uint2*)(R + (r + t) * b.ow4 + 4 * q);
+                const uint32_t g = (uint32_t)P.gk[t];
+                s[0] += g * (v.x & 0xFFFFu); s[1] += g * (v.x >> 16); s[2] += g * (v.y & 0xFFFFu); s[3] += g * (v.y >> 16);
             }
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) packed |= min(s[k] >> 16, 255u) << (8 * k);
+            // bpitch is a multiple of 16 >= w: the <= 3 bytes past w (sums of pad columns) land in row padding
+            *(uint32_t*)(out + (size_t)(b.oy0 + r) * lv.bpitch + b.ox0 + 4 * q) = packed;
+        }
     }
 }
 
