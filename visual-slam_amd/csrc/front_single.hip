@@ -21,8 +21,46 @@
 
 #define FS_NT 1024
 #define FS_BOX_INTS 14
+// own box of a tile on level 0, about: the phases are bound by instruction issue inside a CU, so more, smaller tiles put idle CUs to
+// work until the halo (about 25 px on each side at 8 levels of 1.2) outweighs it (A/B: profiles/r04_ab_front_single_tiles.txt)
+#ifndef FS_TILE_W
+#define FS_TILE_W 48
+#endif
+#ifndef FS_TILE_H
+#define FS_TILE_H 40
+#endif
 #define FS_HDR_INTS (MO_MAX_LEVELS * FS_BOX_INTS + 4)
 #define FS_MAX_LDS (144 * 1024)       // of the 160 KB of a gfx950 CU (the static header lives there too)
+
+// What the kernel needs before it has read a tile's header: the tile grid and the level-0 halo, the same for all tiles (the largest
+// any tile's chain asks for), so that a workgroup derives its level-0 box from its block index alone and fetches header, coefficient
+// entries and level-0 pixels in ONE round trip (two dependent cold ones were 13 of the kernel's 49 k cycles).
+struct FsGeom {
+    int nx, ny;
+    uint32_t inv_nx, inv_ny;  // floor(2^32 / n) + 1: n * W / nx == umulhi(n * W, inv_nx) while n * W * nx < 2^32
+    int hl, hr, ht, hb;       // level-0 halo: columns left / right (multiples of 4), rows above / below the own box
+    int tabmax;               // coefficient entries per tile (the blobs are zero-padded to it); they sit at LDS offset 0
+    int a0_off;               // LDS byte offset of the level-0 box (behind the entries)
+};
+
+static inline __host__ __device__ int fs_cut(int i, int n, int len, uint32_t inv, int mask) {  // tile boundary i of n over [0, len)
+    if (i >= n) return len;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__umulhi((uint32_t)(i * len), inv) & mask;
+#else
+    return (int)(((unsigned long long)(uint32_t)(i * len) * inv) >> 32) & mask;
+#endif
+}
+// level-0 box of tile (tx, ty): own box and extended box [ex0, ex1) x [ey0, ey1)
+static inline __host__ __device__ void fs_box0(const FsGeom& G, int W, int H, int tx, int ty, int& ox0, int& ox1, int& oy0, int& oy1, int& ex0,
+                                               int& ex1, int& ey0, int& ey1) {
+    ox0 = fs_cut(tx, G.nx, W, G.inv_nx, ~3); ox1 = fs_cut(tx + 1, G.nx, W, G.inv_nx, ~3);
+    oy0 = fs_cut(ty, G.ny, H, G.inv_ny, ~0); oy1 = fs_cut(ty + 1, G.ny, H, G.inv_ny, ~0);
+    ex0 = ox0 == 0 ? -4 : max(ox0 - G.hl, 0);
+    ex1 = ox1 == W ? ((W + 3 + 3) & ~3) : min(ox1 + G.hr, (W + 3) & ~3);
+    ey0 = max(oy0 - G.ht, 0);
+    ey1 = min(oy1 + G.hb, H);
+}
 
 // one level of one tile (FS_BOX_INTS ints in the tile's header)
 struct FsBox {
@@ -57,14 +95,25 @@ int fs_build(mo_ctx* c) {
     }
     const LevelInfo& top = P.lv[nl - 1];
     if (top.w < 8 || top.h < 8) return MO_OK;
-    // tiles of about 64 x 60 level-0 pixels, and never narrower than 8 pixels on the coarsest level
-    const int nx = std::max(1, std::min((P.w + 32) / 64, top.w / 8)), ny = std::max(1, std::min((P.h + 30) / 60, top.h / 8));
+    // tiles of about FS_TILE_W x FS_TILE_H level-0 pixels, and never narrower than 8 pixels on the coarsest level
+    const int nx = std::max(1, std::min((P.w + FS_TILE_W / 2) / FS_TILE_W, top.w / 8)), ny = std::max(1, std::min((P.h + FS_TILE_H / 2) / FS_TILE_H, top.h / 8));
     const int ntiles = nx * ny;
-    auto X = [&](int L, int i) { return i >= nx ? P.lv[L].w : (int)(((long long)i * P.lv[L].w / nx) & ~3ll); };
-    auto Y = [&](int L, int j) { return j >= ny ? P.lv[L].h : (int)((long long)j * P.lv[L].h / ny); };
+    FsGeom G = {};
+    G.nx = nx; G.ny = ny;
+    G.inv_nx = (uint32_t)(0x100000000ull / (unsigned)nx) + 1u; G.inv_ny = (uint32_t)(0x100000000ull / (unsigned)ny) + 1u;
+    if ((unsigned long long)nx * P.w * nx >= (1ull << 32) || (unsigned long long)ny * P.h * ny >= (1ull << 32)) return MO_OK;
+    auto X = [&](int L, int i) { return fs_cut(i, nx, P.lv[L].w, G.inv_nx, ~3); };
+    auto Y = [&](int L, int j) { return fs_cut(j, ny, P.lv[L].h, G.inv_ny, ~0); };
+    for (int L = 0; L < nl; L++) {  // the reciprocal form is the plain division (the kernel computes level 0's cuts itself)
+        for (int i = 0; i <= nx; i++) if (X(L, i) != (i >= nx ? P.lv[L].w : (int)(((long long)i * P.lv[L].w / nx) & ~3ll))) return MO_OK;
+        for (int j = 0; j <= ny; j++) if (Y(L, j) != (j >= ny ? P.lv[L].h : (int)((long long)j * P.lv[L].h / ny))) return MO_OK;
+    }
 
+    // two passes over the tiles: the first finds the level-0 halo every tile's chain fits in (and the entry count), the second lays
+    // the tiles out with that common level-0 box
     std::vector<std::vector<uint32_t>> blobs((size_t)ntiles);
     size_t max_ints = 0, max_lds = 0;
+    for (int pass = 0; pass < 2; pass++)
     for (int ty = 0; ty < ny; ty++)
         for (int tx = 0; tx < nx; tx++) {
             FsBox b[MO_MAX_LEVELS] = {};
@@ -96,13 +145,34 @@ int fs_build(mo_ctx* c) {
                 // (row, quad) of task i as (i * inv) >> 20: exact while i * quads < 2^20
                 if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20) || (long long)(v.oy1 - v.oy0 + 6) * (v.ow4 >> 2) * (v.ow4 >> 2) >= (1 << 20)) return MO_OK;
             }
-            // LDS layout: pixels of every level | coefficient entries | blur row sums
-            size_t off = 0;
-            for (int L = 0; L < nl; L++) { b[L].a_off = (int)off; off += ((size_t)b[L].ew * b[L].eh + 15) & ~(size_t)15; }
-            const size_t tab_base = off;
             int nt = 0;
             for (int L = 1; L < nl; L++) { b[L].t_off = nt; nt += b[L].ew + ((b[L].eh + 3) & ~3); }  // 16-byte aligned slices (uint4 reads)
-            off += (((size_t)nt * 4) + 15) & ~(size_t)15;
+            if (pass == 0) {
+                FsBox& v = b[0];
+                if (v.ox0 > 0) G.hl = std::max(G.hl, v.ox0 - v.ex0);
+                if (v.ox1 < P.w) G.hr = std::max(G.hr, v.ex0 + v.ew - v.ox1);
+                G.ht = std::max(G.ht, v.oy0 - v.ey0); G.hb = std::max(G.hb, v.ey0 + v.eh - v.oy1);
+                G.tabmax = std::max(G.tabmax, nt);
+                if (tx == nx - 1 && ty == ny - 1) {
+                    G.tabmax = (G.tabmax + 3) & ~3;
+                    G.a0_off = G.tabmax * 4;
+                }
+                continue;
+            }
+            {  // level 0 takes the common box (fs_box0: what the kernel computes); it must hold what this tile's chain reads
+                FsBox& v = b[0];
+                int ox0, ox1, oy0, oy1, ex0, ex1, ey0, ey1;
+                fs_box0(G, P.w, P.h, tx, ty, ox0, ox1, oy0, oy1, ex0, ex1, ey0, ey1);
+                if (ox0 != v.ox0 || ox1 != v.ox1 || oy0 != v.oy0 || oy1 != v.oy1) return MO_OK;
+                if (ex0 > v.ex0 || ex1 < v.ex0 + v.ew || ey0 > v.ey0 || ey1 < v.ey0 + v.eh) return MO_OK;
+                v.ex0 = ex0; v.ew = ex1 - ex0; v.ey0 = ey0; v.eh = ey1 - ey0;
+                v.inv_e = (1u << 20) / (uint32_t)(v.ew >> 2) + 1u;
+                if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20)) return MO_OK;
+            }
+            // LDS layout: coefficient entries (the same size for all tiles) | pixels of every level | blur row sums
+            const size_t tab_base = 0;
+            size_t off = (size_t)G.a0_off;
+            for (int L = 0; L < nl; L++) { b[L].a_off = (int)off; off += ((size_t)b[L].ew * b[L].eh + 15) & ~(size_t)15; }
             const size_t rs_base = off;
             int nr = 0;
             for (int L = 0; L < nl; L++) { b[L].r_off = nr; nr += ((b[L].oy1 - b[L].oy0 + 6) * b[L].ow4 + 3) & ~3; }
@@ -110,7 +180,7 @@ int fs_build(mo_ctx* c) {
             max_lds = std::max(max_lds, off);
 
             std::vector<uint32_t>& blob = blobs[(size_t)ty * nx + tx];
-            blob.assign((size_t)FS_HDR_INTS + nt, 0u);
+            blob.assign((size_t)FS_HDR_INTS + G.tabmax, 0u);
             for (int L = 0; L < nl; L++) std::memcpy(&blob[(size_t)L * FS_BOX_INTS], &b[L], sizeof(FsBox));
             blob[MO_MAX_LEVELS * FS_BOX_INTS + 0] = (uint32_t)nt;
             blob[MO_MAX_LEVELS * FS_BOX_INTS + 1] = (uint32_t)tab_base;
@@ -150,6 +220,8 @@ int fs_build(mo_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->d_fs_tab, all.size() * sizeof(uint32_t)));
     HIPCHK(c, hipMemcpy(c->d_fs_tab, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->fs_tiles = ntiles;
+    static_assert(sizeof(FsGeom) == sizeof(c->fs_geom), "FsGeom and mo_ctx::fs_geom");
+    std::memcpy(c->fs_geom, &G, sizeof(G));
     c->fs_stride = (int)stride;
     c->fs_lds = (int)max_lds;
     c->fs_ok = true;
@@ -161,43 +233,59 @@ __device__ __forceinline__ uint32_t fs_udot2(uint32_t a, uint32_t b, uint32_t c)
     return __builtin_amdgcn_udot2(__builtin_bit_cast(fs_u16x2, a), __builtin_bit_cast(fs_u16x2, b), c, false);
 }
 
-__global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, const uint32_t* __restrict__ tab, int stride,
+__global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, FsGeom G, const uint32_t* __restrict__ tab, int stride,
                                                         const uint8_t* __restrict__ gray, uint8_t* __restrict__ pyr,
                                                         uint8_t* __restrict__ blur, int want_blur) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ int s_hdr[FS_HDR_INTS];
-    const int tid = threadIdx.x, frame = blockIdx.y, nl = P.nlevels;
-    const uint32_t* blob = tab + (size_t)blockIdx.x * stride;
-    if (tid < FS_HDR_INTS) s_hdr[tid] = (int)blob[tid];
-    __syncthreads();
-    const FsBox* box = (const FsBox*)s_hdr;
-    const int nt = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS], tab_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 1],
-              rs_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 2];
-    uint32_t* s_tab = (uint32_t*)(lds + tab_base);
-    // Every pass below is one loop over the (row, quad) tasks of a box, task i -> row (i * inv) >> 20 (host reciprocal): the phases
-    // are bound by instruction issue, and a fixed thread -> column mapping left a fifth to a half of the lanes without a task.
-
-    // ---- level 0: the extended box out of the frame, and the coefficient entries of all levels, in one round trip
+    const int tid = threadIdx.x, frame = blockIdx.z, nl = P.nlevels;
+    const uint32_t* blob = tab + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * stride;
+    uint32_t* s_tab = (uint32_t*)lds;
+    // ---- header, coefficient entries of all levels and the level-0 box out of the frame (its geometry from the block index:
+    //      fs_box0, the formula the host laid the tile out with), all in one round trip
     {
-        const FsBox b = box[0];
+        int ox0, ox1, oy0, oy1, ex0, ex1, ey0, ey1;
+        fs_box0(G, P.w, P.h, (int)blockIdx.x, (int)blockIdx.y, ox0, ox1, oy0, oy1, ex0, ex1, ey0, ey1);
         const uint8_t* g = gray + (size_t)frame * P.w * P.h;
-        const int qw = b.ew >> 2, n = qw * b.eh;
+        const int ew = ex1 - ex0, qw = ew >> 2, eh = ey1 - ey0;
         const bool al = (P.w & 3) == 0 && (((size_t)g) & 3) == 0;  // (then a quad lies inside the row or in a pad)
-        for (int i = tid; i < n; i += FS_NT) {
-            const int r = (int)(((uint32_t)i * b.inv_e) >> 20), q = i - r * qw, x = b.ex0 + 4 * q;
-            const uint8_t* row = g + (size_t)(b.ey0 + r) * P.w;
-            uint32_t v = 0;
-            if (al) {
-                if (x >= 0 && x < P.w) v = *(const uint32_t*)(row + x);  // (pad quads are filled once the levels are complete)
-            } else {
+        if (tid < FS_HDR_INTS) s_hdr[tid] = (int)blob[tid];
+        for (int i = tid; i < G.tabmax; i += FS_NT) s_tab[i] = blob[FS_HDR_INTS + i];
+        // blocks of 128 rows x 64 quads, 4 x 2 per thread, ALL loads of a block issued before its first LDS store: a loop that
+        // stores each dword before it loads the next made up to six dependent round trips out of this one
+        for (int rb = 0; rb < eh; rb += 128)
+            for (int qb = 0; qb < qw; qb += 64) {
+                uint32_t v[4][2];
 #pragma unroll
-                for (int k = 0; k < 4; k++) v |= (uint32_t)row[min(max(x + k, 0), P.w - 1)] << (8 * k);
+                for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+                    for (int qi = 0; qi < 2; qi++) {
+                        const int r = rb + (tid >> 5) + 32 * ri, q = qb + (tid & 31) + 32 * qi, x = ex0 + 4 * q;
+                        v[ri][qi] = 0;
+                        if (r < eh && q < qw) {
+                            const uint8_t* row = g + (size_t)(ey0 + r) * P.w;
+                            if (al) {
+                                if (x >= 0 && x < P.w) v[ri][qi] = *(const uint32_t*)(row + x);  // (pad quads are filled once the levels are complete)
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 4; k++) v[ri][qi] |= (uint32_t)row[min(max(x + k, 0), P.w - 1)] << (8 * k);
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int ri = 0; ri < 4; ri++)
+#pragma unroll
+                    for (int qi = 0; qi < 2; qi++) {
+                        const int r = rb + (tid >> 5) + 32 * ri, q = qb + (tid & 31) + 32 * qi;
+                        if (r < eh && q < qw) ((uint32_t*)(lds + G.a0_off + r * ew))[q] = v[ri][qi];
+                    }
             }
-            ((uint32_t*)(lds + b.a_off + r * b.ew))[q] = v;
-        }
-        for (int i = tid; i < nt; i += FS_NT) s_tab[i] = blob[FS_HDR_INTS + i];
     }
     __syncthreads();
+    const FsBox* box = (const FsBox*)s_hdr;
+    const int rs_base = s_hdr[MO_MAX_LEVELS * FS_BOX_INTS + 2];
+    // Every pass below is one loop over the (row, quad) tasks of a box, task i -> row (i * inv) >> 20 (host reciprocal): the phases
+    // are bound by instruction issue, and a fixed thread -> column mapping left a fifth to a half of the lanes without a task.
 
     // ---- levels 1 .. : INTER_LINEAR_EXACT from the previous level's box in LDS (k_resize2's arithmetic: row interpolants
     //      (256 - cx) a + cx b < 2^16, then ((256 - cy) h0 + cy h1 + 32768) >> 16); the own part goes to the pyramid slab
@@ -235,17 +323,21 @@ __global__ __launch_bounds__(FS_NT) void k_front_single(Plan P, const uint32_t* 
     }
     if (!want_blur) return;
 
-    // ---- pad columns of the boxes on a level's left / right border: REFLECT_101 (column -k = column k, column W - 1 + k = W - 1 - k)
-    for (int L = 0; L < nl; L++) {
-        const FsBox b = box[L];
-        const int W = P.lv[L].w;
-        const bool left = b.ox0 == 0, right = b.ox1 == W;
-        if (!left && !right) continue;  // block-uniform
-        uint8_t* A = lds + b.a_off - b.ex0;  // indexed by level column
-        for (int r = tid; r < b.eh; r += FS_NT) {
-            uint8_t* row = A + r * b.ew;
-            if (left) { row[-1] = row[1]; row[-2] = row[2]; row[-3] = row[3]; }
-            if (right) { row[W] = row[W - 2]; row[W + 1] = row[W - 3]; row[W + 2] = row[W - 4]; }
+    // ---- pad columns of the boxes on a level's left / right border: REFLECT_101 (column -k = column k, column W - 1 + k = W - 1 - k);
+    //      one task per (level, row), all levels in one pass (level after level: 5.4 k cycles of LDS round trips for ~ 450 rows)
+    {
+        const bool left = box[0].ox0 == 0, right = box[0].ox1 == P.w;  // (a tile is on the same border of every level)
+        if (left || right) {   // block-uniform
+            int total = 0;
+            for (int L = 0; L < nl; L++) total += box[L].eh;
+            for (int t = tid; t < total; t += FS_NT) {
+                int L = 0, r = t;
+                while (r >= box[L].eh) { r -= box[L].eh; L++; }
+                const int W = P.lv[L].w;
+                uint8_t* row = lds + box[L].a_off - box[L].ex0 + r * box[L].ew;  // indexed by level column
+                if (left) { row[-1] = row[1]; row[-2] = row[2]; row[-3] = row[3]; }
+                if (right) { row[W] = row[W - 2]; row[W + 1] = row[W - 3]; row[W + 2] = row[W - 4]; }
+            }
         }
     }
     __syncthreads();
@@ -309,7 +401,9 @@ int orb_launch_front_single(mo_ctx* c, const uint8_t* d_gray, int batch, int wan
         HIPCHK(c, hipFuncSetAttribute((const void*)k_front_single, hipFuncAttributeMaxDynamicSharedMemorySize, FS_MAX_LDS));
         c->lds_attr_done |= 64u;
     }
-    hipLaunchKernelGGL(k_front_single, dim3((unsigned)c->fs_tiles, (unsigned)batch), dim3(FS_NT), (size_t)c->fs_lds, c->stream, c->plan,
+    FsGeom G;
+    std::memcpy(&G, c->fs_geom, sizeof(G));
+    hipLaunchKernelGGL(k_front_single, dim3((unsigned)G.nx, (unsigned)G.ny, (unsigned)batch), dim3(FS_NT), (size_t)c->fs_lds, c->stream, c->plan, G,
                        c->d_fs_tab, c->fs_stride, d_gray, c->d_pyr, c->d_blur, want_blur);
     HIPCHK(c, hipGetLastError());
     return MO_OK;
