@@ -866,7 +866,7 @@ extern "C" int mo_dbg_pyramid_level(mo_ctx* c, const mo_orb_params* p, const uin
     const bool fused = (blurred & 2) != 0;  // bit 1: through the single-frame kernel (front_single.hip) instead of k_resize2 / k_blur
     blurred &= 1;
     if (fused) {
-        if (!c->fs_ok) return mo_fail(c, MO_ERR_UNSUPPORTED, "the single-frame pyramid kernel does not cover this geometry");
+        if (!c->fs_ok) return mo_fail(c, MO_ERR_UNSUPPORTED, std::string("the single-frame pyramid kernel does not cover this geometry: ") + c->fs_why);
         HIPCHK(c, hipMemsetAsync(c->d_pyr, 0xA5, (size_t)c->plan.pyr_stride, c->stream));   // whatever it does not write shows
         HIPCHK(c, hipMemsetAsync(c->d_blur, 0xA5, (size_t)c->plan.blur_stride, c->stream));
         if ((rc = orb_launch_front_single(c, d_gray, 1, 1))) return rc;

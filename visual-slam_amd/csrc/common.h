@@ -103,7 +103,7 @@ struct mo_ctx {
     uint32_t* d_tile_tab[2] = {nullptr, nullptr};          // blur: tile -> level | tile column << 8 | tile row << 20 (built with the plan); [0]: whole levels, [1]: without the margin tile_margin
     int tile_cum[2][MO_MAX_LEVELS + 1] = {};               // tiles of levels < L (the tables are level-major: a prefix blurs the first levels)
     int tile_margin = 0;
-    uint32_t* d_fs_tab = nullptr; int fs_tiles = 0, fs_stride = 0, fs_lds = 0; bool fs_ok = false; int fs_geom[10] = {};  // k_front_single: per-tile headers + coefficient slices (built with the plan)
+    uint32_t* d_fs_tab = nullptr; int fs_tiles = 0, fs_stride = 0, fs_lds = 0; bool fs_ok = false; int fs_geom[10] = {}; const char* fs_why = "";  // k_front_single: per-tile headers + coefficient slices (built with the plan)
     uint32_t* d_strip_tab = nullptr; int n_strip_tab = 0;  // FAST: strip of a frame -> level | strip of the level << 8
     uint32_t* d_dtile_tab = nullptr; int n_dtiles = 0, dtile_icw_off = 0;  // k_describe_tiles: tile -> level | column << 8 | row << 20, then the centroid weights
     int* d_dtodo = nullptr; size_t dtodo_bytes = 0;  // k_describe_tiles -> k_describe_tiles_rare: [0] count, then frame * tiles + tile

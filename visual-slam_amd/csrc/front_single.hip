@@ -80,33 +80,36 @@ static inline int fs_reflect(int p, int len) {
     return p;
 }
 
+// a geometry the kernel does not take: the reason is kept for the probe's message (tools/fuzz_front_single.py tallies them)
+static int fs_no(mo_ctx* c, const char* why) { c->fs_why = why; return MO_OK; }
+
 // Builds the per-tile headers and coefficient slices of the current plan (c->d_fs_tab).  Leaves c->fs_ok false - the callers then
 // take orb_launch_pyramid / orb_launch_blur - when there is nothing to fuse or a tile does not fit in LDS.
 int fs_build(mo_ctx* c) {
-    c->fs_ok = false;
+    c->fs_ok = false; c->fs_why = "";
     if (c->d_fs_tab) { hipFree(c->d_fs_tab); c->d_fs_tab = nullptr; }
     const Plan& P = c->plan;
     const int nl = P.nlevels;
-    if (nl < 2) return MO_OK;
+    if (nl < 2) return fs_no(c, "one level: nothing to chain");
     std::vector<std::vector<int>> xo(nl), xc(nl), yo(nl), yc(nl);
     for (int L = 1; L < nl; L++) {
         mo_linear_coeffs(P.lv[L - 1].w, P.lv[L].w, xo[L], xc[L]);
         mo_linear_coeffs(P.lv[L - 1].h, P.lv[L].h, yo[L], yc[L]);
     }
     const LevelInfo& top = P.lv[nl - 1];
-    if (top.w < 8 || top.h < 8) return MO_OK;
+    if (top.w < 8 || top.h < 8) return fs_no(c, "coarsest level smaller than 8 px");
     // tiles of about FS_TILE_W x FS_TILE_H level-0 pixels, and never narrower than 8 pixels on the coarsest level
     const int nx = std::max(1, std::min((P.w + FS_TILE_W / 2) / FS_TILE_W, top.w / 8)), ny = std::max(1, std::min((P.h + FS_TILE_H / 2) / FS_TILE_H, top.h / 8));
     const int ntiles = nx * ny;
     FsGeom G = {};
     G.nx = nx; G.ny = ny;
     G.inv_nx = (uint32_t)(0x100000000ull / (unsigned)nx) + 1u; G.inv_ny = (uint32_t)(0x100000000ull / (unsigned)ny) + 1u;
-    if ((unsigned long long)nx * P.w * nx >= (1ull << 32) || (unsigned long long)ny * P.h * ny >= (1ull << 32)) return MO_OK;
+    if ((unsigned long long)nx * P.w * nx >= (1ull << 32) || (unsigned long long)ny * P.h * ny >= (1ull << 32)) return fs_no(c, "tile cuts beyond the reciprocal's range");
     auto X = [&](int L, int i) { return fs_cut(i, nx, P.lv[L].w, G.inv_nx, ~3); };
     auto Y = [&](int L, int j) { return fs_cut(j, ny, P.lv[L].h, G.inv_ny, ~0); };
     for (int L = 0; L < nl; L++) {  // the reciprocal form is the plain division (the kernel computes level 0's cuts itself)
-        for (int i = 0; i <= nx; i++) if (X(L, i) != (i >= nx ? P.lv[L].w : (int)(((long long)i * P.lv[L].w / nx) & ~3ll))) return MO_OK;
-        for (int j = 0; j <= ny; j++) if (Y(L, j) != (j >= ny ? P.lv[L].h : (int)((long long)j * P.lv[L].h / ny))) return MO_OK;
+        for (int i = 0; i <= nx; i++) if (X(L, i) != (i >= nx ? P.lv[L].w : (int)(((long long)i * P.lv[L].w / nx) & ~3ll))) return fs_no(c, "tile cut reciprocal inexact (x)");
+        for (int j = 0; j <= ny; j++) if (Y(L, j) != (j >= ny ? P.lv[L].h : (int)((long long)j * P.lv[L].h / ny))) return fs_no(c, "tile cut reciprocal inexact (y)");
     }
 
     // two passes over the tiles: the first finds the level-0 halo every tile's chain fits in (and the entry count), the second lays
@@ -121,15 +124,15 @@ int fs_build(mo_ctx* c) {
                 const int W = P.lv[L].w, H = P.lv[L].h;
                 FsBox& v = b[L];
                 v.ox0 = X(L, tx); v.ox1 = X(L, tx + 1); v.oy0 = Y(L, ty); v.oy1 = Y(L, ty + 1);
-                if (v.ox1 - v.ox0 < 4 || v.oy1 - v.oy0 < 4) return MO_OK;  // (cannot happen with the tile counts above)
+                if (v.ox1 - v.ox0 < 4 || v.oy1 - v.oy0 < 4) return fs_no(c, "own box narrower than 4 px");  // (cannot happen with the tile counts above)
                 v.ow4 = ((v.ox1 + 3) & ~3) - v.ox0;
                 // what the blur of the own box reads.  Columns: own - 3 .. own + 2 as they are; on the level's left / right border these are
                 // the pad columns -3 .. -1 / W .. W + 2, which the kernel fills with the REFLECT_101 pixels once the level is complete, so
                 // that every quad of the row pass reads three aligned dwords (a lane on a per-tap reflection path held its whole wavefront
                 // 16 x longer: 27 of this kernel's first 49 us, profiles/r04_front_single_stamps.txt).  Rows: reflected per row.
                 int lx = v.ox0 - 3, hx = v.ox1 + 2, ly = H, hy = -1;
-                if (v.ox0 > 0 && lx < 0) return MO_OK;
-                if (v.ox1 < W && hx > W - 1) return MO_OK;
+                if (v.ox0 > 0 && lx < 0) return fs_no(c, "blur halo left of the level on an inner tile");
+                if (v.ox1 < W && hx > W - 1) return fs_no(c, "blur halo right of the level on an inner tile");
                 for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); ly = std::min(ly, r); hy = std::max(hy, r); }
                 if (L + 1 < nl) {  // what the next level's extended box (all of it is computed, padding columns included) reads
                     const FsBox& n = b[L + 1];
@@ -143,7 +146,7 @@ int fs_build(mo_ctx* c) {
                 v.ey0 = ly; v.eh = hy + 1 - ly;
                 v.inv_e = (1u << 20) / (uint32_t)(v.ew >> 2) + 1u; v.inv_o = (1u << 20) / (uint32_t)(v.ow4 >> 2) + 1u;
                 // (row, quad) of task i as (i * inv) >> 20: exact while i * quads < 2^20
-                if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20) || (long long)(v.oy1 - v.oy0 + 6) * (v.ow4 >> 2) * (v.ow4 >> 2) >= (1 << 20)) return MO_OK;
+                if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20) || (long long)(v.oy1 - v.oy0 + 6) * (v.ow4 >> 2) * (v.ow4 >> 2) >= (1 << 20)) return fs_no(c, "task count beyond the reciprocal's range");
             }
             int nt = 0;
             for (int L = 1; L < nl; L++) { b[L].t_off = nt; nt += b[L].ew + ((b[L].eh + 3) & ~3); }  // 16-byte aligned slices (uint4 reads)
@@ -163,11 +166,11 @@ int fs_build(mo_ctx* c) {
                 FsBox& v = b[0];
                 int ox0, ox1, oy0, oy1, ex0, ex1, ey0, ey1;
                 fs_box0(G, P.w, P.h, tx, ty, ox0, ox1, oy0, oy1, ex0, ex1, ey0, ey1);
-                if (ox0 != v.ox0 || ox1 != v.ox1 || oy0 != v.oy0 || oy1 != v.oy1) return MO_OK;
-                if (ex0 > v.ex0 || ex1 < v.ex0 + v.ew || ey0 > v.ey0 || ey1 < v.ey0 + v.eh) return MO_OK;
+                if (ox0 != v.ox0 || ox1 != v.ox1 || oy0 != v.oy0 || oy1 != v.oy1) return fs_no(c, "level-0 cuts differ between host and kernel formula");
+                if (ex0 > v.ex0 || ex1 < v.ex0 + v.ew || ey0 > v.ey0 || ey1 < v.ey0 + v.eh) return fs_no(c, "common level-0 box does not hold a tile's chain");
                 v.ex0 = ex0; v.ew = ex1 - ex0; v.ey0 = ey0; v.eh = ey1 - ey0;
                 v.inv_e = (1u << 20) / (uint32_t)(v.ew >> 2) + 1u;
-                if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20)) return MO_OK;
+                if ((long long)v.eh * (v.ew >> 2) * (v.ew >> 2) >= (1 << 20)) return fs_no(c, "level-0 task count beyond the reciprocal's range");
             }
             // LDS layout: coefficient entries (the same size for all tiles) | pixels of every level | blur row sums
             const size_t tab_base = 0;
@@ -194,12 +197,12 @@ int fs_build(mo_ctx* c) {
                 uint32_t* e = &blob[(size_t)FS_HDR_INTS + v.t_off];
                 for (int i = 0; i < v.ew; i++) {
                     const int j = std::min(std::max(v.ex0 + i, 0), W - 1), o = xo[L][j], o1 = std::min(o + 1, SW - 1), rel = o - s.ex0;
-                    if (rel < 0 || rel + (o1 - o) >= s.ew || rel > 0x7FFF) return MO_OK;
+                    if (rel < 0 || rel + (o1 - o) >= s.ew || rel > 0x7FFF) return fs_no(c, "column source index outside the previous level's box");
                     e[i] = (uint32_t)rel | ((uint32_t)(o1 - o) << 15) | ((uint32_t)xc[L][j] << 16);
                 }
                 for (int i = 0; i < v.eh; i++) {
                     const int j = v.ey0 + i, o = yo[L][j], o1 = std::min(o + 1, SH - 1), rel = o - s.ey0;
-                    if (rel < 0 || rel + (o1 - o) >= s.eh || rel > 0x7FFF) return MO_OK;
+                    if (rel < 0 || rel + (o1 - o) >= s.eh || rel > 0x7FFF) return fs_no(c, "row source index outside the previous level's box");
                     e[v.ew + i] = (uint32_t)rel | ((uint32_t)(o1 - o) << 15) | ((uint32_t)yc[L][j] << 16);
                 }
             }
@@ -207,13 +210,13 @@ int fs_build(mo_ctx* c) {
             for (int L = 0; L < nl; L++) {
                 const FsBox& v = b[L];
                 const int W = P.lv[L].w, H = P.lv[L].h;
-                for (int x = v.ox0 - 4; x < v.ox0 + v.ow4 + 3; x++) if (x < v.ex0 || (x >= v.ex0 + v.ew && x < std::min(v.ox1 + 3, W + 3))) return MO_OK;
-                if ((v.ox0 == 0 || v.ox1 == W) && W < 8) return MO_OK;
-                for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); if (r < v.ey0 || r >= v.ey0 + v.eh) return MO_OK; }
+                for (int x = v.ox0 - 4; x < v.ox0 + v.ow4 + 3; x++) if (x < v.ex0 || (x >= v.ex0 + v.ew && x < std::min(v.ox1 + 3, W + 3))) return fs_no(c, "blur columns outside the level's box");
+                if ((v.ox0 == 0 || v.ox1 == W) && W < 8) return fs_no(c, "border level narrower than 8 px");
+                for (int y = v.oy0 - 3; y < v.oy1 + 3; y++) { const int r = fs_reflect(y, H); if (r < v.ey0 || r >= v.ey0 + v.eh) return fs_no(c, "blur rows outside the level's box"); }
             }
             max_ints = std::max(max_ints, blob.size());
         }
-    if (max_lds > FS_MAX_LDS) return MO_OK;
+    if (max_lds > FS_MAX_LDS) return fs_no(c, "a tile's boxes exceed the LDS budget");
     const size_t stride = (max_ints + 3) & ~(size_t)3;
     std::vector<uint32_t> all(stride * ntiles, 0u);
     for (int t = 0; t < ntiles; t++) std::copy(blobs[t].begin(), blobs[t].end(), all.begin() + (size_t)t * stride);
