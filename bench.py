@@ -680,6 +680,16 @@ def main():
                 r = geom.track_from_last_frame(trk["last"][0], trk["last"][1], cur[0], cur[1], K, f1.shape)
                 trk["last"] = cur
                 return r
+            # the same on the detector Tracker.process_frame takes by default (tracker.py:87: extract_features() with distributed=True), in
+            # the aligned form a tracker needs (keypoint i belongs to descriptor row i; the reference's own list holds ALL corners)
+            trg = {"last": ex.distribute_keypoints(f0, aligned=True), "i": 0}
+
+            def tracker_frame_grid():
+                trg["i"] ^= 1
+                cur = ex.distribute_keypoints(f1 if trg["i"] else f0, aligned=True)
+                r = geom.track_from_last_frame(trg["last"][0], trg["last"][1], cur[0], cur[1], K, f1.shape)
+                trg["last"] = cur
+                return r
             from orbslam2.initializer import MapInitializer
             import contextlib, io as _io
 
@@ -693,7 +703,9 @@ def main():
                 "detect_and_compute_all_objects": med_ms(lambda: tuple(ex.detect_and_compute(f0)[0]), 20),
                 "detect_and_compute_native_arrays": med_ms(lambda: ctx1.orb_detect_compute(f0, ex.orb.prm), 20),
                 "extract_features_distributed": med_ms(lambda: ex.extract_features(f0, distributed=True), 10),
-                "tracker_frame": med_ms(tracker_frame, 20)}
+                "extract_features_distributed_all_objects": med_ms(lambda: list(ex.extract_features(f0, distributed=True)[0]), 10),
+                "tracker_frame": med_ms(tracker_frame, 20),
+                "tracker_frame_grid_detector": med_ms(tracker_frame_grid, 20)}
             (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)   # (the last two extractions: both resident)
             out["single_frame_ms"].update({
                 "match_2000x2000": med_ms(lambda: mt.match(d0, d1), 20),
@@ -709,7 +721,9 @@ def main():
                 "BASELINE config 2, median wall ms per call through the drop-in classes, host numpy in / Python objects out: the image goes "
                 "through pinned staging and an upload kernel, results stay resident on the device (tokens) and come back through one pack "
                 "kernel, one synchronisation per call; tracker_frame = what a Tracker pays per frame in TRACKING state: detect_and_compute + "
-                "track_from_last_frame on resident frames (tracker.py:87,198-266); initialize = MapInitializer.initialize as ONE device "
+                "track_from_last_frame on resident frames (tracker.py:87,198-266) with the ORB detector, tracker_frame_grid_detector = the same with "
+                "distribute_keypoints(aligned=True), the detector Tracker.process_frame takes by default; extract_features_distributed returns the "
+                "reference's list of ALL corners as a lazy KeyPointList (*_all_objects forces the objects); initialize = MapInitializer.initialize as ONE device "
                 "call; detect_and_compute returns a lazy KeyPoint sequence (*_all_objects forces all 2000 objects); breakdown: wall and the "
                 "C call's clocks with the stage events off, device spans (hipEvents) of the same call with them on")
             # (d) the same frames as a SEQUENCE through vslam_amd.stream.FrameStream (mo_stream): host frames in, per-frame results out,

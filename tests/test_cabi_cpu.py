@@ -180,6 +180,32 @@ def test_lazy_keypoint_sequence_behaves_like_the_tuple():
     assert sum(1 for _ in reversed(seq)) == 50 and full[3] in seq and seq.index(full[3]) == 3
 
 
+def test_lazy_keypoint_list_behaves_like_the_list(monkeypatch):
+    """orbslam2.types.KeyPointList (what distribute_keypoints / extract_features(distributed=True) return for ALL corners; the reference
+    builds a Python list there, extractor.py:133): the lazy sequence answering like a list for everything the reference's callers do
+    with it (len, indexing, iteration: tracker.py:238-239, tests/test_orb_extractor.py:84-90) plus ==, + and slices; the plain list
+    on request."""
+    from orbslam2.types import KeyPointList, keypoints_at, keypoints_at_lazy, keypoints_to_array
+    xy = np.array([[1.5, 2.5], [10, 20], [30, 40], [7, 9]], np.float32)
+    lazy, plain = keypoints_at_lazy(xy, 31), keypoints_at(xy, 31)
+    assert isinstance(lazy, KeyPointList) and type(plain) is list and len(lazy) == 4 and lazy.pristine
+    assert keypoints_to_array(lazy) is lazy.array                     # no objects, no copy
+    k = lazy[1]
+    assert k is lazy[1] and k is lazy[-3] and not lazy.pristine
+    assert (k.pt, k.size, k.angle, k.response, k.octave, k.class_id) == ((10.0, 20.0), 31.0, -1.0, 0.0, 0, -1)
+    assert [(q.pt, q.size, q.angle, q.octave, q.class_id) for q in lazy] == [(q.pt, q.size, q.angle, q.octave, q.class_id) for q in plain]
+    assert type(lazy[1:3]) is list and lazy[1:3][0] is k and type(lazy + [1]) is list and type([1] + lazy) is list and len(lazy + lazy) == 8
+    assert lazy == list(lazy) and not (lazy == tuple(lazy))           # a list equals lists only
+    with pytest.raises(IndexError):
+        lazy[4]
+    with pytest.raises(TypeError):
+        hash(lazy)
+    empty = keypoints_at_lazy(np.zeros((0, 2), np.float32), 31)
+    assert empty == [] and len(empty) == 0 and list(empty) == [] and not empty
+    monkeypatch.setenv("VSLAM_AMD_KEYPOINTS", "tuple")
+    assert type(keypoints_at_lazy(xy, 31)) is list
+
+
 def test_keypoints_as_plain_tuple_on_request(monkeypatch):
     import vslam_amd as V
     from orbslam2.types import keypoints_from_array

@@ -103,6 +103,21 @@ def main():
     out["tracker_frame_class_wall_ms"] = round(med(tracker_frame, n)[0], 4)
     (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
     out["extract_features_distributed_class_wall_ms"] = round(med(lambda: ex.extract_features(f0, distributed=True), n)[0], 4)
+    # the detector Tracker.process_frame takes by default (reference tracker.py:87: extract_features() with distributed=True): the same
+    # breakdown at the binding, and a tracked frame on it (grid extraction + track_from_last_frame on the resident records)
+    out["grid_detect_compute"] = measure(ctx, lambda: ctx.grid_detect_compute(f0, prm, 2000, records=True), n)
+    out["grid_detect_compute"]["class_wall_ms"] = out["extract_features_distributed_class_wall_ms"]
+    out["grid_detect_compute"]["class_python_ms"] = round(out["extract_features_distributed_class_wall_ms"] - out["grid_detect_compute"]["wall_ms"], 4)
+    gstate = {"last": ex.distribute_keypoints(f0, aligned=True), "i": 0}  # (aligned: keypoint i belongs to descriptor row i, records resident)
+
+    def tracker_frame_grid():
+        gstate["i"] ^= 1
+        cur = ex.distribute_keypoints(f1 if gstate["i"] else f0, aligned=True)
+        r = geom.track_from_last_frame(gstate["last"][0], gstate["last"][1], cur[0], cur[1], K, f1.shape)
+        gstate["last"] = cur
+        return r
+    out["tracker_frame_grid_class_wall_ms"] = round(med(tracker_frame_grid, n)[0], 4)
+    (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
 
     init = MapInitializer(K)
     init.set_first_frame(k0, d0, f0)

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 import vslam_amd
-from .types import keypoints_at, keypoints_from_array, keypoints_to_array
+from .types import keypoints_at_lazy, keypoints_from_array, keypoints_to_array
 
 
 def _default_order():
@@ -77,7 +77,8 @@ class ORBExtractor:
         """Grid-based detection (reference extractor.py:85-144): 8x8 cells, Shi-Tomasi corners per cell
         (maxCorners = n_features // 64, qualityLevel 0.01, minDistance 10), KeyPoint(x, y, 31) each, then
         orb.compute on all of them.  Like the reference, the returned list holds ALL corners while the descriptor
-        rows are those cv2 keeps (corners within 31 px of the border are dropped by compute).
+        rows are those cv2 keeps (corners within 31 px of the border are dropped by compute).  The list is a KeyPointList: records
+        that answer like the reference's list and create a KeyPoint object when one is asked for (VSLAM_AMD_KEYPOINTS=tuple: the plain list).
         aligned=True (an extension, not in the reference): only the kept corners are returned - as a lazy KeyPointSeq, like
         detect_and_compute - so that keypoint i belongs to descriptor row i: what a caller needs to index keypoints with match indices."""
         if n_features is None:
@@ -90,7 +91,7 @@ class ORBExtractor:
             _, kept, descriptors, rec = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features, records=True)
             return KeyPointSeq(rec), (descriptors if len(kept) else None)
         xy, kept, descriptors = vslam_amd.default_context().grid_detect_compute(image, self.orb.prm, n_features)
-        all_keypoints = keypoints_at(xy, 31)  # a list, like the reference's (bulk conversion, slots filled directly)
+        all_keypoints = keypoints_at_lazy(xy, 31)  # the reference's list of ALL corners, as records: an object exists once it is asked for
         if not len(kept):
             descriptors = None
         return all_keypoints, descriptors

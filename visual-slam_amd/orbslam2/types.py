@@ -129,6 +129,47 @@ class KeyPointSeq(_Sequence):
         return self._objs is None and not self._some
 
 
+class KeyPointList(KeyPointSeq):
+    """distribute_keypoints' list of ALL corners.  The reference builds a Python list of cv2.KeyPoint (extractor.py:133) and its
+    callers index it, take its length and hand it on (tracker.py:87-146, 238-239; tests/test_orb_extractor.py:84-90): this is the same
+    lazy sequence answering like a list (== with lists, + and slices give lists; `list(seq)` is the plain list) - 1 400 objects per
+    frame cost 0.29 ms, more than the whole device call (0.11 ms).  What a list has and this has not: it cannot be modified in place."""
+    __slots__ = ()
+
+    def __getitem__(self, i):
+        r = KeyPointSeq.__getitem__(self, i)
+        return list(r) if isinstance(i, slice) else r
+
+    def __eq__(self, other):
+        if isinstance(other, KeyPointSeq):
+            return self._all() == other._all()
+        return isinstance(other, list) and list(self._all()) == other
+
+    __hash__ = None  # (like a list)
+
+    def __add__(self, other):
+        return list(self._all()) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self._all())
+
+    def __repr__(self):
+        return "KeyPointList(%d keypoints)" % len(self.array)
+
+
+def keypoints_at_lazy(xy, size=31.0):
+    """keypoints_at as a KeyPointList over records (the plain list with VSLAM_AMD_KEYPOINTS=tuple, like keypoints_from_array)"""
+    if _os.environ.get("VSLAM_AMD_KEYPOINTS", "lazy").lower() == "tuple":
+        return keypoints_at(xy, size)
+    import numpy as np
+    from vslam_amd import KP_DTYPE
+    rec = np.zeros(len(xy), KP_DTYPE)
+    if len(xy):
+        rec["x"], rec["y"] = xy[:, 0], xy[:, 1]
+    rec["size"], rec["angle"], rec["class_id"] = float(size), -1.0, -1
+    return KeyPointList(rec)
+
+
 def keypoints_from_array(arr):
     """structured mo_keypoint array -> what detectAndCompute returns (cv2: a tuple of KeyPoint; here the lazy KeyPointSeq, or the
     plain tuple with VSLAM_AMD_KEYPOINTS=tuple for a caller that insists on the type)"""
