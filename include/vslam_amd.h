@@ -28,7 +28,7 @@ extern "C" {
  * field: their layout belongs to the header a caller was compiled against.  mo_batch_io gets fields APPENDED per round, so a caller built
  * against an older header hands in a shorter struct than the library reads: every caller must be recompiled with the header of the library
  * it loads, and can check that at load time: mo_abi_version() == MO_ABI_VERSION. */
-#define MO_ABI_VERSION 4
+#define MO_ABI_VERSION 5
 int mo_abi_version(void);
 
 #define MO_OK 0
@@ -350,6 +350,8 @@ mo_stream* mo_stream_create(mo_ctx*, const mo_orb_params*, const mo_stream_param
 void mo_stream_destroy(mo_stream*);
 int mo_stream_submit(mo_stream*, const uint8_t* frames, int n, int stride, size_t frame_stride);
 int mo_stream_collect(mo_stream*, mo_stream_result*);
+int mo_stream_lanes(void);  /* chunks a stream holds in flight: submit refuses one more before a collect; a collected chunk's result
+                               buffer is reused by the mo_stream_lanes()-th submit after it */
 const char* mo_stream_last_error(mo_stream*);
 
 /* ---- multi-GPU: the final map-point gather (SURVEY.md 8b mo_gather_map_points, 8e) --------------------------------------

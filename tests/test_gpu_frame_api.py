@@ -254,10 +254,11 @@ def test_frame_stream_equals_the_per_frame_loop(chunk, detector):
     # (copy=True, the default: the results outlive the stream.  Views of a copy=False stream are refused once their buffer is gone)
     fv = FrameStream(K, chunk=chunk, n_features=2000, cap=2048, detector=V.DETECT_GRID if grid else V.DETECT_ORB, n_hyp=64, copy=False)
     try:
-        stale = list(fv.run(frames[:3 * chunk + 1] if 3 * chunk + 1 <= nfr else np.concatenate([frames, frames])[:3 * chunk + 1]))
+        nst = fv.lanes * chunk + 1                          # one chunk more than there are lanes (mo_stream_lanes)
+        stale = list(fv.run(np.concatenate([frames] * (nst // nfr + 1))[:nst]))
         assert len(stale[-1].keypoints) > 300              # the last chunk's buffer is still there
         with pytest.raises(RuntimeError):
-            stale[0].keypoints                              # chunk 1's lane was reused by chunk 4
+            stale[0].keypoints                              # the first chunk's lane was reused by the last one
     finally:
         fv.close()
     with pytest.raises(RuntimeError):

@@ -89,7 +89,12 @@ struct Lane {
 
 }  // namespace
 
-#define MO_STREAM_LANES 3   // chunks in flight: one being staged / uploaded, one computing, one downloading / being read by the caller
+// chunks in flight: one being staged / uploaded, one computing, one downloading / being read by the caller - and more than that when the
+// caller's own work per chunk sits beside a chunk's latency (staging + upload + compute): the steady-state period is bounded by
+// (latency + caller time per chunk) / (lanes - 1); A/B of 3 / 4 / 5: profiles/r04_ab_stream_lanes.txt.  mo_stream_lanes() reports it.
+#ifndef MO_STREAM_LANES
+#define MO_STREAM_LANES 3
+#endif
 
 struct mo_stream {
     mo_ctx* c = nullptr;
@@ -254,6 +259,8 @@ extern "C" int mo_stream_submit(mo_stream* s, const uint8_t* frames, int n, int 
     s->frames_in += n;
     return MO_OK;
 }
+
+extern "C" int mo_stream_lanes(void) { return MO_STREAM_LANES; }
 
 extern "C" int mo_stream_collect(mo_stream* s, mo_stream_result* r) {
     if (!s || !r) return MO_ERR_ARG;

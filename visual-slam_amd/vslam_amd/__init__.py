@@ -15,7 +15,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("VSLAM_AMD_LIB") or os.path.join(_PKG_ROOT, "libvslam_amd.so")
 
 MO_OK, MO_ERR_ARG, MO_ERR_HIP, MO_ERR_CAPACITY, MO_ERR_UNSUPPORTED = 0, -1, -2, -3, -4
-ABI_VERSION = 4  # MO_ABI_VERSION of include/vslam_amd.h: the struct layouts mirrored below
+ABI_VERSION = 5  # MO_ABI_VERSION of include/vslam_amd.h: the struct layouts mirrored below
 ORDER_LIBSTDCXX, ORDER_MSVC = 0, 1
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
@@ -125,6 +125,7 @@ SIGNATURES = {
     "mo_stream_submit": (_i, [_vp, _vp, _i, _i, C.c_size_t]),
     "mo_stream_collect": (_i, [_vp, _vp]),
     "mo_stream_last_error": (C.c_char_p, [_vp]),
+    "mo_stream_lanes": (_i, []),
     "mo_comm_unique_id": (_i, [_vp]),
     "mo_comm_init": (_i, [_vp, _vp, _i, _i]),
     "mo_comm_destroy": (_i, [_vp]),

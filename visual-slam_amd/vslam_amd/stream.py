@@ -21,7 +21,7 @@ from . import (DETECT_GRID, DETECT_ORB, KP_DTYPE, MODE_INIT, MODE_TRACK, MO_ERR_
                StreamResult, orb_params)
 
 
-LANES = 3   # MO_STREAM_LANES of the library: chunks in flight
+# (chunks in flight = mo_stream_lanes() of the library a stream was created on: FrameStream.lanes)
 
 
 class _Chunk:
@@ -35,7 +35,7 @@ class _Chunk:
         if self.copy:
             return
         st = self.stream
-        if st is None or st.h_stream is None or st._submitted - self.serial >= LANES:
+        if st is None or st.h_stream is None or st._submitted - self.serial >= st.lanes:
             raise RuntimeError("FrameResult of a FrameStream(copy=False) read after its pinned buffer was reused or the stream closed: "
                                "read the arrays while iterating, or create the stream with copy=True")
 
@@ -182,6 +182,8 @@ class FrameStream:
         self.h_stream = self.ctx.lib.mo_stream_create(self.ctx.h, C.byref(self.prm), C.byref(sp))
         if not self.h_stream:
             raise NativeError(-1, self.ctx.lib.mo_last_error(self.ctx.h).decode())
+        lib = self.ctx.lib
+        self.lanes = int(lib.mo_stream_lanes()) if hasattr(lib, "mo_stream_lanes") else 3   # (else: an older build under VSLAM_AMD_LIB)
         self._in_flight = 0
         self._submitted = 0
 
@@ -254,14 +256,14 @@ class FrameStream:
     def run(self, frames):
         """frames: an array (N, H, W[, 3]) uint8 - a frame stack: chunks are handed over as slices, no per-frame copy in Python - or any
         iterable of (H, W[, 3]) uint8 arrays (gathered into chunks frame by frame) -> generator of FrameResult in frame order.  Up to
-        three chunks are in flight: while the GPU works on chunk i and uploads chunk i + 1, the caller consumes the results of chunk i - 1.
+        `self.lanes` chunks are in flight: while the GPU works on chunk i and uploads chunk i + 1, the caller consumes the results of chunk i - 1.
         With copy=False a FrameResult's arrays must be read before two more chunks have been submitted (i.e. while iterating)."""
         if isinstance(frames, np.ndarray) and frames.ndim == (4 if self.ch == 3 else 3):
             for k in range(0, len(frames), self.chunk):
-                if self._in_flight == LANES:
+                if self._in_flight == self.lanes:
                     yield from self.collect()
                 self.submit(frames[k:k + self.chunk])
-                if self._in_flight == LANES:        # (the oldest chunk is read while the two younger ones upload / compute)
+                if self._in_flight == self.lanes:        # (the oldest chunk is read while the two younger ones upload / compute)
                     yield from self.collect()
             while self._in_flight:
                 yield from self.collect()
@@ -273,14 +275,14 @@ class FrameStream:
             block[fill] = fr
             fill += 1
             if fill == self.chunk:
-                if self._in_flight == LANES:
+                if self._in_flight == self.lanes:
                     yield from self.collect()
                 self.submit(block)   # (staged into pinned memory inside the call: the block is refilled at once)
                 fill = 0
-                if self._in_flight == LANES:
+                if self._in_flight == self.lanes:
                     yield from self.collect()
         if fill:
-            if self._in_flight == LANES:
+            if self._in_flight == self.lanes:
                 yield from self.collect()
             self.submit(block[:fill])
         while self._in_flight:
