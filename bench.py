@@ -739,7 +739,11 @@ def main():
                 fs = FrameStream(K, width=W, height=H, n_features=NFEAT, cap=CAP, n_hyp=N_HYP, **kw)
                 try:
                     src = (lambda a: iter(a)) if name.endswith("_iterator") else (lambda a: a)
-                    n_seen = sum(1 for _ in fs.run(src(host_frames[:4 * kw["chunk"] + 2])))   # (warm-up: plan, lanes, clocks)
+                    # warm-up, untimed: plan and lanes - and, for the FIRST stream of the process, the three ~ 6 ms host stalls of the runtime's
+                    # download call at its chunks 2, 6 and 11 (profiles/r04_stream_where.txt, r04_ab_stream_d2h.txt), which a 5-chunk warm-up left
+                    # inside this leg's 32 timed chunks
+                    n_warm = (16 if not legs else 4) * kw["chunk"] + 2
+                    n_seen = sum(1 for _ in fs.run(src(host_frames[:n_warm])))
                     t1 = time.perf_counter()
                     n_seen, n_in = 0, 0
                     for r in fs.run(src(host_frames)):
@@ -755,6 +759,7 @@ def main():
                 legs[name] = {"value": round(n_seen / el, 1), "unit": "frames/s", "frames": n_seen, "ms_per_chunk": round(el / n_seen * kw["chunk"] * 1e3, 3)}
             legs["note"] = ("FrameStream (mo_stream) over a 2048-frame pageable host frame stack (N, H, W) built from the bench's frames, H2D-inclusive: "
                             "staging into pinned memory (pool of host threads), upload stream, one mo_dev_frontend_batch per chunk in tracking mode "
+                            "(each leg after an untimed warm-up pass on the same stream: 16 chunks for the first stream of the process, 4 for the others) "
                             "(ratio test, 2 filters, 8-pt RANSAC %d hyp at 1 px), download stream, three chunks in flight, one Python FrameResult per "
                             "frame whose pose and inlier flags the loop reads (feature arrays touched on every 16th frame); result arrays are views of "
                             "the pinned buffers except in *_copies (the caller's own copies, made per chunk); *_iterator: frames arrive one by one from a "

@@ -253,6 +253,10 @@ extern "C" int mo_stream_submit(mo_stream* s, const uint8_t* frames, int n, int 
     const size_t upto = s->p.mode == MO_MODE_TRACK && !s->p.want_matches ? s->o_midx : s->p.want_points ? s->out_bytes : s->o_pts;
     SCHK(s, hipEventRecord(l.computed, c->stream));
     SCHK(s, hipStreamWaitEvent(s->down_s, l.computed, 0));
+    // This call, 4 us as a rule, holds the host for 5.6 - 7.3 ms at chunks 2, 6 and 11 of the FIRST stream of a process and never again (later
+    // streams, new contexts included, are flat): a first run of 64 chunks reads 47 - 52 k frames/s where the steady rate is 60 k.  Tried
+    // (profiles/r04_ab_stream_d2h.txt): a copy kernel into a mapped buffer - no stalls, but it shares the CUs with the next chunk's compute:
+    // 51.6 k against 60 k frames/s in steady state; a dozen result-sized downloads at creation - the stalls stay where they were.
     SCHK(s, hipMemcpyAsync(l.h_out, o, upto, hipMemcpyDeviceToHost, s->down_s));
     SCHK(s, hipEventRecord(l.done, s->down_s));
     s->submitted++;
