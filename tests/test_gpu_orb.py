@@ -424,6 +424,29 @@ def test_response_ties_beyond_the_level_slot_grow_the_slots(O):
         O.lib().orc_set_variant(1, 0)
 
 
+def test_tall_frame_in_a_single_frame_context(O):
+    """A context for one frame at a time cuts the FAST strips to 2 rows (more workgroups, a shorter chain per call); a level may have at most
+    2047 strips.  The tallest frame mo_create accepts, 4095 rows, has 2017 two-row strips on level 0 - just below that - and must give the
+    oracle's result, as the same frame does in a context built for batches (8-row strips, 505 of them)."""
+    import vslam_amd as V
+    w, h = 256, 4095
+    img = synthetic_frame(404, w, h)
+    O.lib().orc_set_variant(0, 0)
+    p, o = _prm(V, O, 0, nfeatures=3000, fast_threshold=9)
+    ek, ed = O.detect_and_compute(img, o)
+    assert len(ek) > 1500
+    for max_batch in (1, 8):
+        ctx = V.Context(device=0, max_w=w, max_h=h, max_batch=max_batch)
+        try:
+            (k, d), = ctx.orb_detect_compute(img, p)
+        finally:
+            ctx.close()
+        for f in ("x", "y", "size", "angle", "response", "octave"):
+            assert np.array_equal(k[f], ek[f]), (max_batch, f)
+        assert np.array_equal(d, ed), max_batch
+    O.lib().orc_set_variant(1, 0)
+
+
 def test_4k_frame(O):
     """3840 x 2160 (263 FAST strips on level 0: above the 256 the selection kernel's prefix table held until round 3; level 0 alone
     has several hundred thousand candidates): detect_and_compute, the grid detector and the matcher on the result, bit-exact."""

@@ -11,6 +11,13 @@
 #define MO_MAX_LEVELS 12
 #define MO_HALF_PATCH 15
 #define MO_STRIP_ROWS 8
+// rows per FAST strip in a context for one or two frames at a time (max_batch <= 2): such a call waits for the longest strip's chain, so
+// shorter strips on more workgroups cut it (FAST stage of one 640x480 frame: 26.3 / 18.2 / 15.5 / 14.2 us at 8 / 4 / 3 / 2 rows; the
+// selection's gather pays 2 us for the extra strips; 1 row: slower again; profiles/r04_ab_strip_rows_single.txt)
+#ifndef MO_STRIP_ROWS_LATENCY
+#define MO_STRIP_ROWS_LATENCY 2
+#endif
+#define SEL_MAXSTRIPS 2047  // strips of one level that k_select's prefix table (dynamic LDS, behind the record window) holds
 
 // per-level geometry, uploaded by value as a kernel argument
 struct LevelInfo {

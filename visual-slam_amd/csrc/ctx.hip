@@ -292,8 +292,13 @@ int mo_build_plan(mo_ctx* c, const mo_orb_params* p, int w, int h, int batch) {
         if (v.w <= 2 * et || v.h <= 2 * et) { v.bx0 = v.by0 = et; v.bw = v.bh = 0; }
         else { v.bx0 = et; v.by0 = et; v.bw = v.w - 2 * et; v.bh = v.h - 2 * et; }
         v.inv_bw = v.bw > 1 ? 0xFFFFFFFFu / (uint32_t)v.bw + 1u : 0u;
-        v.strip_rows = MO_STRIP_ROWS;
+        // (a context for one or two frames at a time: shorter strips, more workgroups - MO_STRIP_ROWS_LATENCY in common.h)
+        v.strip_rows = c->max_batch <= 2 ? MO_STRIP_ROWS_LATENCY : MO_STRIP_ROWS;
         while (v.strip_rows > 1 && v.strip_rows * v.bw > 16384) v.strip_rows /= 2;
+        // (short strips only while the level stays below the selection kernel's strip limit; mo_create caps frames at 4095 px = 2017 two-row
+        //  strips, so this matters only if that cap is raised)
+        while (v.strip_rows < MO_STRIP_ROWS && v.bh > 0 && (v.bh + v.strip_rows - 1) / v.strip_rows > SEL_MAXSTRIPS && 2 * v.strip_rows * v.bw <= 16384)
+            v.strip_rows *= 2;
         if (v.bw > 16384) return mo_fail(c, MO_ERR_UNSUPPORTED, "level too wide");
         v.nstrips = v.bh > 0 ? (v.bh + v.strip_rows - 1) / v.strip_rows : 0;
         v.strip_cap = ((v.strip_rows + 1) / 2) * ((v.bw + 1) / 2);

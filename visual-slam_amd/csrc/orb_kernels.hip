@@ -868,7 +868,7 @@ int orb_launch_fast(mo_ctx* c, const uint8_t* d_gray, int batch, int level_lo, i
 #define SEL_BUF_BYTES (SEL_BUF_KB * 1024)  // LDS record window (u32 FAST records, then u64 Harris records overlaid): holds the ~9000 candidates a
                                    // dense 640x480 level 0 produces (5.125 B each with the replay's side arrays; SURVEY 8d texture: 6600 -
                                    // 7000); 3 workgroups per CU with the 3.4 KB of Harris windows and the replay scratch
-#define SEL_MAXSTRIPS 2047  // strips of one level (8K frames: 540); their prefix table lies behind the record window in dynamic LDS
+// (SEL_MAXSTRIPS, the strips of one level - 8K frames: 540 at 8 rows -, is in common.h: mo_build_plan keeps a level below it)
 
 // Harris response of a 7x7 block on the raw level (orb.cpp HarrisResponses): int sums, float32 formula
 __device__ float harris_response(const uint8_t* img, int pitch, int x0, int y0) {
