@@ -1278,6 +1278,9 @@ __device__ __forceinline__ uint16_t rbrief_u16_lds(uint32_t lds_base, int ppitch
 #define DT_BLR_ROWS (DT_H + 38)
 #ifndef DT_NT
 #define DT_NT 256                    // 16 keypoint groups of 16 lanes
+#ifndef DT_SPLIT_LATENCY
+#define DT_SPLIT_LATENCY 4           // workgroups per tile in calls on one or two frames (a power of two)
+#endif
 #endif
 #ifdef DT_WAVES
 #define DT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(DT_WAVES, 8)))
@@ -1324,7 +1327,8 @@ __device__ __forceinline__ void tile_load_bytes(const uint8_t* img, int pitch, i
 // passes each, both tiles fetched again for every pass).  Two kernels because the generic loop beside the one-pass form costs the
 // latter 34 registers (125 instead of 91: 4 instead of 5 wavefronts per SIMD).
 template <bool HAS_DESC, bool RARE>
-__device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile, int tiles_per_frame, const uint32_t* __restrict__ tile_tab,
+__device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile, int tiles_per_frame, int split, int nsplit /* power of two */,
+                                              const uint32_t* __restrict__ tile_tab,
                                               const uint8_t* __restrict__ gray, const uint8_t* __restrict__ pyr,
                                               const uint8_t* __restrict__ blur, const FinalKp* __restrict__ fin_all,
                                               const int* __restrict__ fin_cnt, mo_keypoint* __restrict__ kps,
@@ -1358,7 +1362,7 @@ __device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile
             total += n;
         }
     }
-    if (!RARE && tile == 0 && tid == 0) {
+    if (!RARE && tile == 0 && split == 0 && tid == 0) {
         counts[frame] = total;
         if (total > cap) atomicOr(&flags[0], 2);
     }
@@ -1403,13 +1407,15 @@ __device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile
     const int row_b_w = gl == 15 ? 0 : 1;  // lane 15's second row is row 15 again: counted once
     const uint32_t tile_lds = (uint32_t)(uintptr_t)s_tile;
 
-    // the chunk's records of this thread that fall into the tile -> list (sub >= 0: only record slot `sub` of the thread)
+    // the chunk's records of this thread that fall into the tile -> list (sub >= 0: only record slot `sub` of the thread).  When nsplit
+    // workgroups share the tile (calls on one or two frames), workgroup `split` lists the records whose index in the LEVEL's list is in its
+    // residue class - a property every workgroup computes alike; the position in s_list is not one (atomicAdd order)
     auto select = [&](int c0, int sub) {
 #pragma unroll
         for (int u = 0; u < DT_CHUNK / DT_NT; u++) {
             const int i = c0 + tid + u * DT_NT;
             const int dx = (int)fk[u].x - x0, dy = (int)fk[u].y - y0;
-            if ((sub < 0 || u == sub) && i < nL && (unsigned)dx < DT_W && (unsigned)dy < DT_H) {
+            if ((sub < 0 || u == sub) && i < nL && (unsigned)dx < DT_W && (unsigned)dy < DT_H && (i & (nsplit - 1)) == split) {
                 const int pos = atomicAdd(&s_n, 1);
                 if (pos < DT_LIST) {
                     s_list[pos] = (uint32_t)(i - c0) | ((uint32_t)dx << 9) | ((uint32_t)dy << 17);
@@ -1499,7 +1505,8 @@ __device__ __forceinline__ void describe_tile(const Plan& P, int frame, int tile
         __syncthreads();
         const int n0 = s_n;
         if (nL > DT_CHUNK || n0 > DT_LIST) {  // block-uniform: left to k_describe_tiles_rare
-            if (tid == 0) todo[1 + atomicAdd(&todo[0], 1)] = frame * tiles_per_frame + tile;
+            // (a long level list is seen by all sharing workgroups alike: one entry; an overflow of its own list by the workgroup that has it)
+            if (tid == 0 && (split == 0 || n0 > DT_LIST)) todo[1 + atomicAdd(&todo[0], 1)] = frame * tiles_per_frame + tile;
             return;
         }
         phase_a(0, n0);
@@ -1551,7 +1558,7 @@ __global__ __launch_bounds__(DT_NT) DT_WAVES_ATTR void k_describe_tiles(Plan P, 
                                                           const uint32_t* __restrict__ icw, int* __restrict__ todo) {
     int frame = blockIdx.y, tile = blockIdx.x;
     xcd_map(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, inv_per, gridDim.y, frame, tile);  // XCD affinity (speed only)
-    describe_tile<HAS_DESC, false>(P, frame, tile, (int)gridDim.x, tile_tab, gray, pyr, blur, fin_all, fin_cnt, kps, desc, cap, counts, flags, icw, todo);
+    describe_tile<HAS_DESC, false>(P, frame, tile, (int)gridDim.x, (int)blockIdx.z, (int)gridDim.z, tile_tab, gray, pyr, blur, fin_all, fin_cnt, kps, desc, cap, counts, flags, icw, todo);
 }
 
 // the tiles the one-pass kernel left over (todo[0] of them, usually none: the workgroups then leave at once); todo[0] is cleared by the
@@ -1566,7 +1573,7 @@ __global__ __launch_bounds__(DT_NT) void k_describe_tiles_rare(Plan P, const uin
     const int n = todo[0];
     for (int e = blockIdx.x; e < n; e += gridDim.x) {  // block-uniform
         const int ft = todo[1 + e];
-        describe_tile<HAS_DESC, true>(P, ft / tiles_per_frame, ft % tiles_per_frame, tiles_per_frame, tile_tab, gray, pyr, blur, fin_all, fin_cnt, kps,
+        describe_tile<HAS_DESC, true>(P, ft / tiles_per_frame, ft % tiles_per_frame, tiles_per_frame, 0, 1, tile_tab, gray, pyr, blur, fin_all, fin_cnt, kps,
                                       desc, cap, counts, flags, icw, todo);
     }
 }
@@ -1603,11 +1610,14 @@ int orb_launch_describe(mo_ctx* c, const uint8_t* d_gray, int batch, mo_keypoint
         HIPCHK(c, hipMemsetAsync(d_counts, 0, (size_t)batch * sizeof(int), c->stream));
         return MO_OK;
     }
-    const dim3 grid(c->n_dtiles, batch);
+    // one or two frames: DT_SPLIT_LATENCY workgroups per tile, each describing the keypoints of one residue class of the level's list.  A coarse
+    // level is one or two tiles holding all of its ~ 120 keypoints - eight passes of 16 in one workgroup while most CUs sit idle; the tile is
+    // loaded once per sharing workgroup, which costs nothing there (profiles/r04_ab_describe_split.txt)
+    const dim3 grid(c->n_dtiles, batch, batch <= 2 ? DT_SPLIT_LATENCY : 1);
     const uint32_t inv_per = grid.x > 1 ? 0xFFFFFFFFu / grid.x + 1u : 0u;
     // todo list of the tiles the one-pass kernel leaves to k_describe_tiles_rare: [0] count (cleared by k_select of the same call), then
     // frame * tiles + tile entries; sized for every tile of the largest batch
-    const size_t todo_need = (1 + (size_t)c->n_dtiles * c->batch_alloc) * sizeof(int);
+    const size_t todo_need = (1 + (size_t)c->n_dtiles * c->batch_alloc * DT_SPLIT_LATENCY) * sizeof(int);  // (each sharing workgroup may leave an entry)
     if (c->dtodo_bytes < todo_need) {
         if (c->d_dtodo) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(c->d_dtodo)); c->d_dtodo = nullptr; c->dtodo_bytes = 0; }
         HIPCHK(c, hipMalloc((void**)&c->d_dtodo, todo_need));
