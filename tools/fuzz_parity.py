@@ -48,9 +48,11 @@ def main(argv=None):
     ap.add_argument("--n", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--budget-s", type=float, default=400.0)
+    ap.add_argument("--max-batch", type=int, default=5, help="frames the context is created for; <= 2: the plan of single-frame contexts "
+                    "(2-row FAST strips) and batches of 1 .. max-batch frames only")
     args = ap.parse_args(argv)
     rng = np.random.Generator(np.random.PCG64(args.seed))
-    ctx = V.Context(device=0, max_w=1000, max_h=800, max_batch=5)
+    ctx = V.Context(device=0, max_w=1000, max_h=800, max_batch=args.max_batch)
     bad, done, t0 = 0, 0, time.time()
     tally = {}
     for it in range(args.n):
@@ -62,7 +64,7 @@ def main(argv=None):
                   nlevels=int(rng.integers(1, 9)), fast_threshold=int(rng.choice([0, 1, 5, 7, 7, 20, 40, 100])),
                   edge_threshold=int(rng.choice([31, 31, 31, 19, 25, 40])))
         order = int(rng.integers(0, 2))
-        nb = int(rng.choice([1, 1, 1, 2, 3, 5]))
+        nb = min(int(rng.choice([1, 1, 1, 2, 3, 5])), args.max_batch)
         names, imgs = zip(*[scene(rng, w, h) for _ in range(nb)])
         cfg = dict(it=it, w=w, h=h, order=order, scenes=names, **kw)
         O.lib().orc_set_variant(order, 0)
