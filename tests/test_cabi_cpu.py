@@ -206,6 +206,42 @@ def test_lazy_keypoint_list_behaves_like_the_list(monkeypatch):
     assert type(keypoints_at_lazy(xy, 31)) is list
 
 
+def test_lazy_match_list_behaves_like_the_list(monkeypatch):
+    """orbslam2.types.DMatchList (what DescriptorMatcher.match, track_from_last_frame and MapInitializer.initialize return; the reference
+    builds Python lists of cv2.DMatch: matcher.py:60-107): len / index / slice / iteration / == / + like a list, objects on demand with a
+    stable identity, the arrays for the drop-in's own filters - whose array form must keep the reference's order (sorted() is stable)."""
+    from orbslam2.types import DMatchList, dmatches_from_arrays, match_arrays
+    rng = np.random.default_rng(3)
+    n = 200
+    q, t, d = rng.permutation(500)[:n], rng.integers(0, 500, n), rng.integers(0, 40, n).astype(np.float64)   # (many equal distances)
+    lazy = dmatches_from_arrays(q, t, d)
+    assert isinstance(lazy, DMatchList) and len(lazy) == n and lazy.pristine and match_arrays(lazy)[0] is lazy.q and lazy.pristine
+    m = lazy[5]
+    assert m is lazy[5] and m is lazy[-195] and not lazy.pristine
+    assert (m.queryIdx, m.trainIdx, m.imgIdx, m.distance) == (int(q[5]), int(t[5]), 0, float(d[5])) and type(m.queryIdx) is int and type(m.distance) is float
+    full = list(lazy)
+    assert full[5] is m and lazy == full and not (lazy == tuple(full)) and type(lazy[2:6]) is list and lazy[2:6] == full[2:6]
+    assert type(lazy + [1]) is list and type([1] + lazy) is list and len(lazy + lazy) == 2 * n
+    qa, ta, da = match_arrays(lazy)                                   # (objects were handed out: read off them)
+    assert np.array_equal(qa, q) and np.array_equal(ta, t) and np.array_equal(da, d)
+    with pytest.raises(IndexError):
+        lazy[n]
+    with pytest.raises(TypeError):
+        hash(lazy)
+    empty = dmatches_from_arrays([], [], [])
+    assert empty == [] and not empty and list(empty) == []
+    # filter_matches_by_distance on arrays == the reference's sorted(...) / median / comprehension on objects
+    ref_sorted = sorted(full, key=lambda x: x.distance)
+    thr = np.median([x.distance for x in ref_sorted]) * 2.0
+    ref = [x for x in ref_sorted if x.distance < thr]
+    fresh = dmatches_from_arrays(q, t, d)
+    order = np.argsort(fresh.d, kind="stable")
+    got = [fresh[i] for i in order[fresh.d[order] < np.median(fresh.d) * 2.0].tolist()]
+    assert [(x.queryIdx, x.trainIdx, x.distance) for x in got] == [(x.queryIdx, x.trainIdx, x.distance) for x in ref] and len(ref) > 50
+    monkeypatch.setenv("VSLAM_AMD_KEYPOINTS", "tuple")
+    assert type(dmatches_from_arrays(q, t, d)) is list
+
+
 def test_keypoints_as_plain_tuple_on_request(monkeypatch):
     import vslam_amd as V
     from orbslam2.types import keypoints_from_array

@@ -114,9 +114,9 @@ class MapInitializer:
                 print(f"Not enough matches for initialization: {len(putative)} < {self.min_matches}")
                 return self._failure(putative)
             K = self.camera_matrix
-            q = np.array([m.queryIdx for m in putative], np.intp)
-            tr = np.array([m.trainIdx for m in putative], np.intp)
-            dist = np.array([m.distance for m in putative], np.float64)
+            from .types import match_arrays
+            q, tr, dist = match_arrays(putative)   # (the arrays of an untouched match list, else read off the DMatch objects)
+            q, tr = q.astype(np.intp), tr.astype(np.intp)
             xy_ref = _pixels(ref_kps, q)
             xy_cur = _pixels(current_keypoints, tr)
             # essential matrix at 3 px, recoverPose and the triangulation of the pose-mask survivors with P = K [I | 0], K [R | t]

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 import vslam_amd
-from .types import DMatch, dmatches_from_arrays, points_of
+from .types import DMatch, dmatches_from_arrays, match_arrays, points_of
 
 
 class _NativeBFMatcher:
@@ -67,34 +67,37 @@ class DescriptorMatcher:
             return []
         # the reference's per-match math.hypot(dx, dy) <= limit on Python floats (float64 of the float32 coordinates): vectorised,
         # with the matches within rounding distance of the limit decided by math.hypot itself
-        a = points_of(keypoints1, [m.queryIdx for m in matches]).astype(np.float64)
-        b = points_of(keypoints2, [m.trainIdx for m in matches]).astype(np.float64)
+        q, t, _ = match_arrays(matches)  # (the arrays of an untouched match list; no DMatch object is created for the rejected ones)
+        a = points_of(keypoints1, q).astype(np.float64)
+        b = points_of(keypoints2, t).astype(np.float64)
         dx, dy = b[:, 0] - a[:, 0], b[:, 1] - a[:, 1]
         dist = np.hypot(dx, dy)
         near = dist <= limit
         for i in np.flatnonzero(np.abs(dist - limit) <= 1e-9 * max(limit, 1.0)).tolist():
             near[i] = math.hypot(dx[i], dy[i]) <= limit
-        return [m for m, ok in zip(matches, near.tolist()) if ok]
+        return [matches[i] for i in np.flatnonzero(near).tolist()]
 
     def filter_matches_by_distance(self, matches, distance_threshold=None):
         if not matches:
             return []
-        ordered = sorted(matches, key=lambda m: m.distance)
+        _, _, d = match_arrays(matches)
+        order = np.argsort(d, kind="stable")  # sorted(matches, key=lambda m: m.distance): stable, ties keep their order
         if distance_threshold is None:
-            distance_threshold = np.median([m.distance for m in ordered]) * 2.0
-        return [m for m in ordered if m.distance < distance_threshold]
+            distance_threshold = np.median(d) * 2.0
+        return [matches[i] for i in order[d[order] < distance_threshold].tolist()]
 
     def filter_matches_by_fundamental(self, keypoints1, keypoints2, matches, threshold=3.0):
         """matcher.py:171-200: cv2.findFundamentalMat(points1, points2, FM_RANSAC, threshold, 0.99) -> (inlier matches, bool mask);
         fewer than 8 matches are returned unfiltered with an all-true mask, like the reference."""
         if len(matches) < 8:
             return matches, np.ones(len(matches), dtype=bool)
-        points1 = points_of(keypoints1, [m.queryIdx for m in matches])
-        points2 = points_of(keypoints2, [m.trainIdx for m in matches])
+        q, t, _ = match_arrays(matches)
+        points1 = points_of(keypoints1, q)
+        points2 = points_of(keypoints2, t)
         F, mask = vslam_amd.default_context().find_fundamental(points1, points2, thr_px=threshold, prob=0.99)
         if F is None:  # cv2 returns mask None here and the reference would raise on mask.ravel(); no model -> no inliers
             return [], np.zeros(len(matches), dtype=bool)
-        return [m for m, inlier in zip(matches, mask) if inlier], mask
+        return [matches[i] for i in np.flatnonzero(np.asarray(mask).ravel()).tolist()], mask
 
     def draw_matches(self, img1, keypoints1, img2, keypoints2, matches, flags=0):
         from .types import HAVE_CV2

@@ -210,12 +210,9 @@ def points_of(kps, indices):
     return np.float32([kps[i].pt for i in indices]).reshape(-1, 2)
 
 
-def dmatches_from_arrays(query, train, distance):
-    """three equal-length arrays -> list of DMatch(queryIdx, trainIdx, 0, distance), Python scalars in bulk conversions; the
-    stand-in class gets its slots filled directly (a quarter less time than 1000 __init__ calls with their int() / float())"""
-    import numpy as np
-    q, t = np.asarray(query).tolist(), np.asarray(train).tolist()
-    d = np.asarray(distance, dtype=np.float64).tolist()
+def _dmatch_objects(q, t, d):
+    """lists of Python scalars -> list of DMatch(queryIdx, trainIdx, 0, distance); the stand-in class gets its slots filled directly
+    (a quarter less time than 1000 __init__ calls with their int() / float())"""
     if HAVE_CV2:
         return [DMatch(a, b, 0, c) for a, b, c in zip(q, t, d)]
     new, out = object.__new__, []
@@ -225,3 +222,93 @@ def dmatches_from_arrays(query, train, distance):
         m.queryIdx = a; m.trainIdx = b; m.imgIdx = 0; m.distance = c
         append(m)
     return out
+
+
+class DMatchList(_Sequence):
+    """The matches of one call (DescriptorMatcher.match, the tracking helpers, MapInitializer): the reference builds a Python list of cv2.DMatch;
+    this is that list over three arrays (query index, train index, distance), answering like a list (len, indexing, slices, iteration, == with
+    lists, +) and creating a DMatch object when one is asked for - 750 objects cost 0.1 ms of a 0.16 ms match call, 250 a tenth of a tracked
+    frame, and the drop-in classes' own filters read the arrays.  An object handed out stays the object of its index; `list(seq)` is the plain
+    list.  What a list has and this has not: it cannot be modified in place."""
+    __slots__ = ("q", "t", "d", "_objs", "_some")
+
+    def __init__(self, query, train, distance):
+        import numpy as np
+        self.q = np.ascontiguousarray(query, dtype=np.int64)
+        self.t = np.ascontiguousarray(train, dtype=np.int64)
+        self.d = np.ascontiguousarray(distance, dtype=np.float64)
+        self._objs = None       # list of all objects once a caller iterated
+        self._some = None       # {index: object} handed out one by one before that
+
+    def __len__(self):
+        return len(self.q)
+
+    def _all(self):
+        if self._objs is None:
+            objs = _dmatch_objects(self.q.tolist(), self.t.tolist(), self.d.tolist())
+            if self._some:
+                for i, m in self._some.items():
+                    objs[i] = m
+            self._objs, self._some = objs, None
+        return self._objs
+
+    def __getitem__(self, i):
+        if self._objs is not None:
+            r = self._objs[i]
+            return list(r) if isinstance(i, slice) else r
+        if isinstance(i, slice):
+            return list(self._all()[i])
+        n = len(self.q)
+        j = int(i)
+        if j < 0:
+            j += n
+        if not 0 <= j < n:
+            raise IndexError("list index out of range")
+        if self._some is None:
+            self._some = {}
+        m = self._some.get(j)
+        if m is None:
+            m = self._some[j] = _dmatch_objects([int(self.q[j])], [int(self.t[j])], [float(self.d[j])])[0]
+        return m
+
+    def __iter__(self):
+        return iter(self._all())
+
+    def __eq__(self, other):
+        if isinstance(other, DMatchList):
+            return self._all() == other._all()
+        return isinstance(other, list) and self._all() == other
+
+    __hash__ = None  # (like a list)
+
+    def __add__(self, other):
+        return self._all() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self._all()
+
+    def __repr__(self):
+        return "DMatchList(%d matches)" % len(self.q)
+
+    @property
+    def pristine(self):
+        """no object was handed out: the arrays are the whole truth (an object a caller holds may have been written to)"""
+        return self._objs is None and not self._some
+
+
+def match_arrays(matches):
+    """(queryIdx, trainIdx, distance) of a match list as arrays: the arrays of an untouched DMatchList, else read off the objects"""
+    import numpy as np
+    if isinstance(matches, DMatchList) and matches.pristine:
+        return matches.q, matches.t, matches.d
+    return (np.array([m.queryIdx for m in matches], np.int64), np.array([m.trainIdx for m in matches], np.int64),
+            np.array([m.distance for m in matches], np.float64))
+
+
+def dmatches_from_arrays(query, train, distance):
+    """three equal-length arrays -> the list of DMatch(queryIdx, trainIdx, 0, distance) as a DMatchList (objects on demand); the plain list
+    with VSLAM_AMD_KEYPOINTS=tuple, like keypoints_from_array"""
+    import numpy as np
+    if _os.environ.get("VSLAM_AMD_KEYPOINTS", "lazy").lower() == "tuple":
+        return _dmatch_objects(np.asarray(query).tolist(), np.asarray(train).tolist(), np.asarray(distance, dtype=np.float64).tolist())
+    return DMatchList(query, train, distance)
