@@ -717,6 +717,8 @@ def main():
             (k0, d0), (k1, d1) = ex.detect_and_compute(f0), ex.detect_and_compute(f1)
             out["single_frame_ms"]["breakdown"]["track_pair_resident"] = breakdown(lambda: ctx1.track_pair(k0.array, d0, k1.array, d1, W, H, K))
             out["single_frame_ms"]["breakdown"]["match_resident"] = breakdown(lambda: ctx1.match_knn2_ratio(d0, d1, 0.75))
+            # (the call behind extract_features(distributed=True), which Tracker.process_frame makes for every frame: tracker.py:87)
+            out["single_frame_ms"]["breakdown"]["grid_detect_compute"] = breakdown(lambda: ctx1.grid_detect_compute(f0, ex.orb.prm, NFEAT, records=True))
             out["single_frame_ms"]["note"] = (
                 "BASELINE config 2, median wall ms per call through the drop-in classes, host numpy in / Python objects out: the image goes "
                 "through pinned staging and an upload kernel, results stay resident on the device (tokens) and come back through one pack "
